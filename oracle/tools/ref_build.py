@@ -1,0 +1,64 @@
+"""Build the *reference* models (imported from /root/reference through ref_shims) with the
+deterministic filler weights, and the synthetic inputs shared by goldens / oracle / product.
+TEST INFRASTRUCTURE -- authoring container only."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+for p in (HERE, REPO, os.path.join(REPO, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import ref_shims  # noqa: E402
+from imagine360_amd.weights import fill_module_  # noqa: E402
+from imagine360_amd.synthetic import icosahedron_cameras, mv_inputs  # noqa: E402,F401
+from im360_oracle.cfg import UNetCfg, VAECfg  # noqa: E402
+
+YAML_UNET_KWARGS = dict(
+    use_motion_module=True, use_inflated_groupnorm=True, motion_module_resolutions=(1, 2, 4, 8),
+    motion_module_mid_block=True, motion_module_type="Vanilla",
+    motion_module_kwargs=dict(num_attention_heads=8, num_transformer_block=1,
+                              attention_block_types=("Temporal_Self", "Temporal_Self"),
+                              temporal_position_encoding=True, temporal_position_encoding_max_len=64,
+                              temporal_attention_dim_div=1, zero_initialize=True),
+    unet_use_cross_frame_attention=False, unet_use_temporal_attention=False, use_linear_projection=True,
+    use_fps_condition=True, use_relative_postions="WithAdapter", use_ip_plus_cross_attention=True,
+    ip_plus_condition="video", num_tokens=64, use_adapter_temporal_projection=True,
+    compress_video_features=True, image_hidden_size=256, use_outpaint=True)
+
+
+def ref_unet(cfg: UNetCfg):
+    R = ref_shims.ref_modules()
+    return R["UNet3DConditionModel"](
+        sample_size=96, in_channels=4, out_channels=4, block_out_channels=tuple(cfg.block_out_channels),
+        layers_per_block=cfg.layers_per_block, attention_head_dim=tuple(cfg.attention_head_dim),
+        cross_attention_dim=cfg.cross_attention_dim, norm_num_groups=cfg.norm_num_groups,
+        norm_eps=cfg.norm_eps, **YAML_UNET_KWARGS)
+
+
+def ref_mv(cfg: UNetCfg):
+    R = ref_shims.ref_modules()
+    mv = R["MultiViewBaseModel"](ref_unet(cfg), ref_unet(cfg), pano_pad=True)
+    fill_module_(mv)
+    return mv.eval()
+
+
+def ref_vae(cfg: VAECfg):
+    R = ref_shims.ref_modules()
+    vae = R["AutoencoderKL"](
+        in_channels=3, out_channels=3, latent_channels=4, block_out_channels=tuple(cfg.block_out_channels),
+        layers_per_block=cfg.layers_per_block, norm_num_groups=cfg.norm_num_groups, sample_size=768,
+        down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4)
+    fill_module_(vae)
+    return vae.eval()
+
+
+def ref_scheduler():
+    R = ref_shims.ref_modules()
+    return R["DDIMScheduler"](num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                              beta_schedule="linear", steps_offset=1, clip_sample=False,
+                              prediction_type="v_prediction", rescale_betas_zero_snr=True)
