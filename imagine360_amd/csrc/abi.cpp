@@ -1,0 +1,83 @@
+// C-ABI plumbing of libim360_kernels.so: error reporting, version, per-kernel-class HIP-event
+// profiling used by bench.py's roofline leg.  No torch types, no allocation of user data, no
+// synchronisation except in im360_prof_collect (which exists to read event timings).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+
+#include "prof.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void im360_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* im360_last_error(void) { return g_err; }
+
+extern "C" int im360_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Slot { hipEvent_t a, b; int kind; };
+std::mutex g_mu;
+std::vector<Slot> g_used, g_free;
+unsigned g_mask = 0;
+}  // namespace
+
+extern "C" void im360_prof_enable(unsigned mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_mask = mask;
+}
+
+namespace im360 {
+ProfScope::ProfScope(int kind, void* stream) : slot_(-1), stream_(stream) {
+    if (!(g_mask & (1u << kind))) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot s;
+    if (!g_free.empty()) {
+        s = g_free.back();
+        g_free.pop_back();
+    } else {
+        if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    }
+    s.kind = kind;
+    hipEventRecord(s.a, (hipStream_t)stream);
+    g_used.push_back(s);
+    slot_ = (int)g_used.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEventRecord(g_used[slot_].b, (hipStream_t)stream_);
+}
+}  // namespace im360
+
+// Sums the elapsed time of every recorded launch of `kind` since the last collect; blocks on the events.
+extern "C" int im360_prof_collect(int kind, double* total_ms, long* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    double tot = 0.0;
+    long n = 0;
+    std::vector<Slot> keep;
+    for (auto& s : g_used) {
+        if (s.kind != kind) {
+            keep.push_back(s);
+            continue;
+        }
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            tot += ms;
+            ++n;
+        }
+        g_free.push_back(s);
+    }
+    g_used.swap(keep);
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return 0;
+}

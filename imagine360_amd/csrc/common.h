@@ -1,0 +1,89 @@
+// Shared device helpers for the gfx950 kernels of imagine360_amd.  CDNA4 only (wave64, MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "prof.h"
+
+namespace im360 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- element type traits: T is __bf16 or _Float16 (16-bit storage, fp32 math) ---------------
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Elem<_Float16> {
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// pack two fp32 into one dword of two T (lo = first element in memory)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    T a = (T)lo, b = (T)hi;
+    uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
+    return (uint32_t)ua | ((uint32_t)ub << 16);
+}
+template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t w) {
+    uint16_t u = (uint16_t)(w & 0xffffu);
+    return (float)__builtin_bit_cast(T, u);
+}
+template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t w) {
+    uint16_t u = (uint16_t)(w >> 16);
+    return (float)__builtin_bit_cast(T, u);
+}
+template <typename T> __device__ __forceinline__ void unpack8(uint4 v, float* f) {
+    f[0] = unpack_lo<T>(v.x); f[1] = unpack_hi<T>(v.x);
+    f[2] = unpack_lo<T>(v.y); f[3] = unpack_hi<T>(v.y);
+    f[4] = unpack_lo<T>(v.z); f[5] = unpack_hi<T>(v.z);
+    f[6] = unpack_lo<T>(v.w); f[7] = unpack_hi<T>(v.w);
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2<T>(f[0], f[1]); v.y = pack2<T>(f[2], f[3]);
+    v.z = pack2<T>(f[4], f[5]); v.w = pack2<T>(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// The MFMA 32x32x16 C/D fragment: lane l, register r holds C[row][col] with
+//   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+}  // namespace im360
+
+// status codes of the C ABI
+#define IM360_OK 0
+#define IM360_ERR_ARG (-1)
+#define IM360_ERR_UNSUPPORTED (-2)
+#define IM360_ERR_LAUNCH (-3)
+
+extern "C" void im360_set_error(const char* fmt, ...);
+#define IM360_CHECK_ARG(cond, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            im360_set_error(__VA_ARGS__);      \
+            return IM360_ERR_ARG;              \
+        }                                      \
+    } while (0)
+#define IM360_CHECK_LAUNCH()                                          \
+    do {                                                              \
+        hipError_t e_ = hipGetLastError();                            \
+        if (e_ != hipSuccess) {                                       \
+            im360_set_error("launch failed: %s", hipGetErrorString(e_)); \
+            return IM360_ERR_LAUNCH;                                  \
+        }                                                             \
+    } while (0)

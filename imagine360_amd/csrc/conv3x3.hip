@@ -1,0 +1,283 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on channels-last 16-bit activations for gfx950 (CDNA4 MFMA).
+//
+// Replaces the reference's per-frame nn.Conv2d call sites (InflatedConv3d is nn.Conv2d on
+// '(b f) c h w', animatediff/models/resnet.py:19-27): ResnetBlock3D conv1/conv2/conv_shortcut
+// (resnet.py:183-218), Downsample3D (stride 2, resnet.py:117-140), Upsample3D (nearest x2 folded into
+// the input index, resnet.py:71-114), conv_in / conv_out (unet.py:134-137, 358) and the VAE convs.
+// The equirectangular circular pad that the reference materialises around every pano conv
+// (src/utils/pano.py:75-101, MVGenModel.py:138-143 ...) is folded into the addressing:
+//   wrap  = 1 : the conv grid is circular along W (pad -> conv -> unpad with unpad >= 1)
+//   x_off > 0 : output column j reads the (already W+4 wide) input at j + x_off (ResnetBlock conv2,
+//               which must see the padded conv1 output because GroupNorm-2 statistics include it)
+// Epilogue fuses bias, the time-embedding add (resnet.py:231-234) and the residual/shortcut add
+// (resnet.py:248-251).
+//
+// GEMM view: D^T[cout, pixel] = W[cout, (tap, cin)] * X^T[(tap, cin), pixel]; 128 x 128 tile per
+// 256-thread workgroup, 4 waves as 2 x 2, each wave 2 x 2 v_mfma_f32_32x32x16 tiles (64 fp32
+// accumulators), K-step = BK channels of one tap, register prefetch of step s+1 under the MFMAs of
+// step s, padded LDS pitch (BK + 8) so ds_read_b128 fragments are bank-conflict free.
+#include "common.h"
+
+namespace im360 {
+
+struct ConvParams {
+    const void* x; const void* w; const void* bias; const void* temb; const void* res; void* y;
+    int N, Hin, Win, Cin, Hout, Wout, Cout;
+    int ntaps;          // 9 (3x3) or 1 (1x1)
+    int stride, up, wrap, x_off;
+    int imgs_per_temb;
+    long M;             // N * Hout * Wout
+    int tiles_n;        // ceil(Cout / 128)
+    long nblocks;
+};
+
+constexpr int BM = 128, BN = 128;
+
+template <typename T, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    constexpr int PITCH = BK + 8;
+    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+    constexpr int LD = (128 * CPR) / 256;       // chunks per thread per operand (2 for BK=32, 4 for BK=64)
+    constexpr int KC = BK / 16;
+    __shared__ __attribute__((aligned(16))) T a_lds[BM * PITCH];   // activations [pixel][k]
+    __shared__ __attribute__((aligned(16))) T b_lds[BN * PITCH];   // weights     [cout][k]
+
+    // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
+    long bid = blockIdx.x;
+    {
+        const long nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long tile_m = bid / p.tiles_n;
+    const int tile_n = (int)(bid % p.tiles_n);
+    const long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int Hc = p.up ? 2 * p.Hin : p.Hin, Wc = p.up ? 2 * p.Win : p.Win;
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+
+    // per-thread pixel coordinates of the activation chunks this thread stages
+    int pn[LD], py[LD], pxx[LD], pc8[LD], prow[LD];
+    bool pvalid[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+        const int c = tid + i * 256;
+        prow[i] = c / CPR;
+        pc8[i] = c % CPR;
+        const long m = m0 + prow[i];
+        pvalid[i] = m < p.M;
+        const long mm = pvalid[i] ? m : 0;
+        pxx[i] = (int)(mm % p.Wout);
+        const long t = mm / p.Wout;
+        py[i] = (int)(t % p.Hout);
+        pn[i] = (int)(t / p.Hout);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int ksteps_per_tap = p.Cin / BK;
+    const int nsteps = p.ntaps * ksteps_per_tap;
+    uint4 areg[LD], breg[LD];
+
+    auto load_step = [&](int s) {
+        const int tap = s / ksteps_per_tap;
+        const int c0 = (s % ksteps_per_tap) * BK;
+        const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            int gy = py[i] * p.stride + dy - 1;
+            int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
+            bool ok = pvalid[i] && gy >= 0 && gy < Hc;
+            if (p.wrap) {
+                gx = gx % Wc;
+                if (gx < 0) gx += Wc;
+            } else {
+                ok = ok && gx >= 0 && gx < Wc;
+            }
+            if (ok) {
+                const int sy = gy >> p.up, sx = gx >> p.up;
+                v = *(const uint4*)(xg + (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0 + pc8[i] * 8);
+            }
+            areg[i] = v;
+            breg[i] = *(const uint4*)(wg + ((long)(n0 + prow[i]) * p.ntaps + tap) * p.Cin + c0 + pc8[i] * 8);
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            *(uint4*)(a_lds + prow[i] * PITCH + pc8[i] * 8) = areg[i];
+            *(uint4*)(b_lds + prow[i] * PITCH + pc8[i] * 8) = breg[i];
+        }
+    };
+
+    load_step(0);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();
+        store_step();
+        __syncthreads();
+        if (s + 1 < nsteps) load_step(s + 1);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            uint4 wf[2], xf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                wf[a] = *(const uint4*)(b_lds + (wn * 64 + a * 32 + col) * PITCH + kc * 16 + hi * 8);
+                xf[a] = *(const uint4*)(a_lds + (wm * 64 + a * 32 + col) * PITCH + kc * 16 + hi * 8);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = Elem<T>::mfma32(wf[a], xf[b], acc[a][b]);
+        }
+    }
+
+    // ---- epilogue: lane (pixel = col, hi) holds 4 consecutive couts per register group
+    const T* bias = (const T*)p.bias;
+    const T* temb = (const T*)p.temb;
+    const T* res = (const T*)p.res;
+    T* yg = (T*)p.y;
+    const bool vec = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const long m = m0 + wm * 64 + b * 32 + col;
+        if (m >= p.M) continue;
+        const long img = m / ((long)p.Hout * p.Wout);
+        const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + wn * 64 + a * 32 + 8 * g + 4 * hi;
+                if (co >= p.Cout) continue;
+                float f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
+                if (vec) {
+                    if (bias) {
+                        const uint2 w = *(const uint2*)(bias + co);
+                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
+                    }
+                    if (trow) {
+                        const uint2 w = *(const uint2*)(trow + co);
+                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
+                    }
+                    if (res) {
+                        const uint2 w = *(const uint2*)(res + m * p.Cout + co);
+                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(f[0], f[1]);
+                    o.y = pack2<T>(f[2], f[3]);
+                    *(uint2*)(yg + m * p.Cout + co) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (co + j < p.Cout) {
+                            float vv = f[j];
+                            if (bias) vv += to_f32(bias[co + j]);
+                            if (trow) vv += to_f32(trow[co + j]);
+                            if (res) vv += to_f32(res[m * p.Cout + co + j]);
+                            yg[m * p.Cout + co + j] = from_f32<T>(vv);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+    if (p.Cin % 64 == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// weights [Cout, Cin, kh, kw] (PyTorch) -> [CoutPad128][kh*kw][CinPad] zero padded, K contiguous
+template <typename T>
+__global__ void pack_conv_weight_kernel(const T* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int taps,
+                                        int CoutPad, int CinPad) {
+    const long total = (long)CoutPad * taps * CinPad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinPad);
+        const long t2 = i / CinPad;
+        const int tap = (int)(t2 % taps);
+        const int co = (int)(t2 / taps);
+        T v = from_f32<T>(0.f);
+        if (co < Cout && ci < Cin) v = w[((long)co * Cin + ci) * taps + tap];
+        out[i] = v;
+    }
+}
+
+}  // namespace im360
+
+extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
+                              const void* res, void* y,
+                              int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                              int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off,
+                              int64_t imgs_per_temb, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w_packed && y, "conv_fwd: null pointer");
+    IM360_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cout > 0, "conv_fwd: empty problem");
+    IM360_CHECK_ARG(Cin > 0 && (Cin % 32) == 0, "conv_fwd: Cin=%ld must be a multiple of 32 (pad channels)", (long)Cin);
+    IM360_CHECK_ARG(ntaps == 9 || ntaps == 1, "conv_fwd: ntaps must be 9 or 1");
+    IM360_CHECK_ARG(stride == 1 || stride == 2, "conv_fwd: stride must be 1 or 2");
+    IM360_CHECK_ARG(!(up && stride != 1), "conv_fwd: upsample input requires stride 1");
+    IM360_CHECK_ARG(!temb || imgs_per_temb > 0, "conv_fwd: imgs_per_temb must be positive");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 8) == 0,
+                    "conv_fwd: misaligned pointer");
+    ConvParams p;
+    p.x = x; p.w = w_packed; p.bias = bias; p.temb = temb; p.res = res; p.y = y;
+    p.N = (int)N; p.Hin = (int)Hin; p.Win = (int)Win; p.Cin = (int)Cin;
+    p.Hout = (int)Hout; p.Wout = (int)Wout; p.Cout = (int)Cout; p.ntaps = (int)ntaps;
+    p.stride = (int)stride; p.up = up ? 1 : 0; p.wrap = wrap ? 1 : 0; p.x_off = (int)x_off;
+    p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
+    p.M = N * Hout * Wout;
+    p.tiles_n = (int)((Cout + BN - 1) / BN);
+    p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+    IM360_CHECK_ARG(p.nblocks <= 0x7fffffffL, "conv_fwd: problem too large");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_CONV, stream);
+    if (dtype == 0) return launch_conv<__bf16>(p, s);
+    if (dtype == 1) return launch_conv<_Float16>(p, s);
+    im360_set_error("conv_fwd: dtype %d unsupported", dtype);
+    return IM360_ERR_UNSUPPORTED;
+}
+
+extern "C" int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,
+                                      int64_t CoutPad, int64_t CinPad, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(w && out, "pack_conv_weight: null pointer");
+    IM360_CHECK_ARG(CoutPad >= Cout && CinPad >= Cin && (CoutPad % 128) == 0 && (CinPad % 32) == 0,
+                    "pack_conv_weight: CoutPad %% 128 and CinPad %% 32 required");
+    const long total = CoutPad * taps * CinPad;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL((pack_conv_weight_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)w, (__bf16*)out,
+                           (int)Cout, (int)Cin, (int)taps, (int)CoutPad, (int)CinPad);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((pack_conv_weight_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)w,
+                           (_Float16*)out, (int)Cout, (int)Cin, (int)taps, (int)CoutPad, (int)CinPad);
+    else {
+        im360_set_error("pack_conv_weight: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}

@@ -1,0 +1,292 @@
+// GroupNorm (+ SiLU, + equirectangular circular pad) on channels-last 16-bit activations, gfx950.
+//
+// Replaces InflatedGroupNorm / nn.GroupNorm + SiLU call sites (animatediff/models/resnet.py:9-17,
+// 224-225, 236-243; Transformer3DModel.norm attention.py:206,262; TemporalTransformer3DModel.norm
+// motion_module.py:128,169; conv_norm_out unet.py:350-356; the VAE norms) and fuses the reference's
+// pad_pano (src/utils/pano.py:75-95) into the apply pass.
+//
+// Parity trap reproduced on purpose: in the pano branch the reference pads BEFORE the ResnetBlock, so
+// norm1 statistics are taken over the circularly padded tensor (the `pad` wrapped columns count twice,
+// MVGenModel.py:277-278).  `pad` > 0 gives those columns weight 2 in the statistics and makes the
+// apply pass write the W + 2*pad wide padded tensor directly.
+//
+// Three HBM-bound passes: (1) per-(image, slab) per-channel partial sums, (2) finalize per-(image,
+// channel) scale/shift in fp64 from the partials, (3) y = act(x * scale + shift).
+#include "common.h"
+
+namespace im360 {
+
+// ---- pass 1 -----------------------------------------------------------------------------------
+// grid (S, N), 256 threads.  partial[n][s][0][c] = sum w*x, partial[n][s][1][c] = sum w*x^2
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                          int HW, int W, int C, int pad, int S) {
+    __shared__ float red[256 * 16];
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int nch = C >> 3;
+    const int pps = (HW + S - 1) / S;
+    const int pix0 = s * pps, pix1 = min(HW, pix0 + pps);
+    const T* xb = x + (long)n * HW * C;
+    for (int c0 = 0; c0 < nch; c0 += 256) {
+        const int ncp = min(256, nch - c0);
+        const int lanes = 256 / ncp;
+        const int cc = tid % ncp, pl = tid / ncp;
+        float acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (pl < lanes) {
+            for (int pix = pix0 + pl; pix < pix1; pix += lanes) {
+                float f[8];
+                unpack8<T>(*(const uint4*)(xb + (long)pix * C + (c0 + cc) * 8), f);
+                float wgt = 1.f;
+                if (pad > 0) {
+                    const int xx = pix % W;
+                    if (xx < pad || xx >= W - pad) wgt = 2.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc[e] += wgt * f[e];
+                    acc[8 + e] += wgt * f[e] * f[e];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[tid * 16 + e] = acc[e];
+        __syncthreads();
+        if (pl == 0) {
+            for (int l = 1; l < lanes; ++l)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] += red[(l * ncp + cc) * 16 + e];
+            float* dst = partial + ((long)(n * S + s) * 2) * C + (c0 + cc) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                dst[e] = acc[e];
+                dst[C + e] = acc[8 + e];
+            }
+        }
+    }
+}
+
+// ---- pass 2 -----------------------------------------------------------------------------------
+template <typename T>
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, const T* __restrict__ gamma,
+                                   const T* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                   int N, int C, int G, int S, double count, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * C) return;
+    const int n = (int)(i / C), c = (int)(i % C);
+    const int cpg = C / G, g = c / cpg;
+    double sum = 0.0, sq = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const float* src = partial + ((long)(n * S + s) * 2) * C + g * cpg;
+        for (int j = 0; j < cpg; ++j) {
+            sum += (double)src[j];
+            sq += (double)src[C + j];
+        }
+    }
+    const double mean = sum / count;
+    double var = sq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
+    scale[i] = (float)(rstd * ga);
+    shift[i] = (float)(be - mean * rstd * ga);
+}
+
+// ---- pass 3 -----------------------------------------------------------------------------------
+// grid (S, N).  out[n][y][x'][c] = act(x[n][y][(x' - pad) mod W][c] * scale[n][c] + shift[n][c]),
+// x' in [0, W + 2 pad)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T* __restrict__ y,
+                                                        int H, int W, int C, int pad, int act, int S) {
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int nch = C >> 3;
+    const int Wo = W + 2 * pad;
+    const int HWo = H * Wo;
+    const int pps = (HWo + S - 1) / S;
+    const int pix0 = s * pps, pix1 = min(HWo, pix0 + pps);
+    const T* xb = x + (long)n * H * W * C;
+    T* yb = y + (long)n * HWo * C;
+    for (int c0 = 0; c0 < nch; c0 += 256) {
+        const int ncp = min(256, nch - c0);
+        const int lanes = 256 / ncp;
+        const int cc = tid % ncp, pl = tid / ncp;
+        if (pl >= lanes) continue;
+        float sc[8], sh[8];
+        const float* sp = scale + (long)n * C + (c0 + cc) * 8;
+        const float* hp = shift + (long)n * C + (c0 + cc) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = sp[e];
+            sh[e] = hp[e];
+        }
+        for (int pix = pix0 + pl; pix < pix1; pix += lanes) {
+            int sx = pix % Wo - pad;
+            const int sy = pix / Wo;
+            if (sx < 0) sx += W;
+            else if (sx >= W) sx -= W;
+            float f[8];
+            unpack8<T>(*(const uint4*)(xb + ((long)sy * W + sx) * C + (c0 + cc) * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = f[e] * sc[e] + sh[e];
+                f[e] = act ? silu_f(v) : v;
+            }
+            *(uint4*)(yb + (long)pix * C + (c0 + cc) * 8) = pack8<T>(f);
+        }
+    }
+}
+
+// ---- circular pad along W of a channels-last tensor (latent boundary of the VAE decode,
+//      pipeline_animation_inference_dual.py:349-357, 813-815) ----------------------------------------
+template <typename T>
+__global__ void circular_pad_w_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int W, int C8, int pad) {
+    const int Wo = W + 2 * pad;
+    const long total = rows * Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        const long t = i / C8;
+        int sx = (int)(t % Wo) - pad;
+        const long row = t / Wo;
+        sx %= W;
+        if (sx < 0) sx += W;
+        ((uint4*)y)[i] = ((const uint4*)x)[(row * W + sx) * C8 + c];
+    }
+}
+
+// ---- CFG combine + DDIM v-prediction update (eta = 0), one elementwise pass
+//      (pipeline_animation_inference_dual.py:791-800; diffusers/schedulers/scheduling_ddim.py:300-350):
+//      v = u + g (c - u);  x_prev = cx * x + cv * v   with cx, cv precomputed on the host in fp64
+template <typename T>
+__global__ void cfg_ddim_kernel(const T* __restrict__ uncond, const T* __restrict__ cond, const T* __restrict__ x,
+                                T* __restrict__ out, long n8, float g, float cx, float cv) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float u[8], c[8], s[8];
+        unpack8<T>(((const uint4*)uncond)[i], u);
+        unpack8<T>(((const uint4*)cond)[i], c);
+        unpack8<T>(((const uint4*)x)[i], s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = cx * s[e] + cv * (u[e] + g * (c[e] - u[e]));
+        ((uint4*)out)[i] = pack8<T>(s);
+    }
+}
+
+static inline int pick_slabs(long N, long HW) {
+    long s = (2048 + N - 1) / N;
+    const long maxs = HW / 64 > 0 ? HW / 64 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+}  // namespace im360
+
+extern "C" int64_t im360_gn_num_slabs(int64_t N, int64_t H, int64_t W) { return im360::pick_slabs(N, H * W); }
+
+// x [N,H,W,C]; partial: fp32 workspace of N * S * 2 * C floats with S = im360_gn_num_slabs(N,H,W);
+// scale, shift: fp32 [N, C] outputs.
+extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, void* partial,
+                                     void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C,
+                                     int64_t G, int64_t pad, float eps, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && gamma && beta && partial && scale && shift, "groupnorm_stats: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && G > 0, "groupnorm_stats: empty problem");
+    IM360_CHECK_ARG((C % 8) == 0 && (C % G) == 0, "groupnorm_stats: C=%ld must be a multiple of 8 and of G=%ld", (long)C, (long)G);
+    IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_stats: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0, "groupnorm_stats: misaligned x");
+    IM360_CHECK_ARG(N <= 65535, "groupnorm_stats: N=%ld exceeds grid.y", (long)N);
+    const int S = pick_slabs(N, H * W);
+    const double count = (double)H * (double)(W + 2 * pad) * (double)(C / G);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GN_STATS, stream);
+    const unsigned fb = (unsigned)((N * C + 255) / 256);
+    if (dtype == 0) {
+        hipLaunchKernelGGL((gn_partial_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const __bf16*)x,
+                           (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
+        hipLaunchKernelGGL((gn_finalize_kernel<__bf16>), dim3(fb), dim3(256), 0, s, (const float*)partial,
+                           (const __bf16*)gamma, (const __bf16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
+                           (int)G, S, count, eps);
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL((gn_partial_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const _Float16*)x,
+                           (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
+        hipLaunchKernelGGL((gn_finalize_kernel<_Float16>), dim3(fb), dim3(256), 0, s, (const float*)partial,
+                           (const _Float16*)gamma, (const _Float16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
+                           (int)G, S, count, eps);
+    } else {
+        im360_set_error("groupnorm_stats: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// y [N, H, W + 2 pad, C] = act(x * scale + shift) with circular W addressing; act: 0 none, 1 SiLU
+extern "C" int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
+                                     int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
+                                     int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && scale && shift && y, "groupnorm_apply: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "groupnorm_apply: bad shape");
+    IM360_CHECK_ARG(pad >= 0 && pad <= W, "groupnorm_apply: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "groupnorm_apply: misaligned pointer");
+    IM360_CHECK_ARG(N <= 65535, "groupnorm_apply: N=%ld exceeds grid.y", (long)N);
+    const int S = pick_slabs(N, H * (W + 2 * pad));
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GN_APPLY, stream);
+    if (dtype == 0)
+        hipLaunchKernelGGL((gn_apply_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const __bf16*)x,
+                           (const float*)scale, (const float*)shift, (__bf16*)y, (int)H, (int)W, (int)C, (int)pad, act, S);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((gn_apply_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const _Float16*)x,
+                           (const float*)scale, (const float*)shift, (_Float16*)y, (int)H, (int)W, (int)C, (int)pad, act, S);
+    else {
+        im360_set_error("groupnorm_apply: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// x [rows, W, C] -> y [rows, W + 2 pad, C], circular along W (16-bit elements, C % 8 == 0)
+extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
+                                    int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && y, "circular_pad_w: null pointer");
+    IM360_CHECK_ARG(rows > 0 && W > 0 && C > 0 && (C % 8) == 0 && pad >= 0, "circular_pad_w: bad shape");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "circular_pad_w: dtype %d unsupported", dtype);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "circular_pad_w: misaligned pointer");
+    const long total = rows * (W + 2 * pad) * (C / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL((circular_pad_w_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, (__bf16*)y, (long)rows, (int)W, (int)(C / 8), (int)pad);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// out = cx * x + cv * (uncond + g (cond - uncond)), n elements (n % 8 == 0), all same dtype
+extern "C" int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
+                                     float guidance, float cx, float cv, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(uncond && cond && x && out, "cfg_ddim_update: null pointer");
+    IM360_CHECK_ARG(n > 0 && (n % 8) == 0, "cfg_ddim_update: n=%ld must be a positive multiple of 8", (long)n);
+    IM360_CHECK_ARG(((uintptr_t)uncond % 16) == 0 && ((uintptr_t)cond % 16) == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0, "cfg_ddim_update: misaligned pointer");
+    const long n8 = n / 8;
+    const unsigned blocks = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL((cfg_ddim_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)uncond,
+                           (const __bf16*)cond, (const __bf16*)x, (__bf16*)out, n8, guidance, cx, cv);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((cfg_ddim_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)uncond,
+                           (const _Float16*)cond, (const _Float16*)x, (_Float16*)out, n8, guidance, cx, cv);
+    else {
+        im360_set_error("cfg_ddim_update: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}

@@ -1,0 +1,234 @@
+"""torch-tensor front end of libim360_kernels.so (C ABI in include/im360_kernels.h).
+
+Every function here launches a hand-written gfx950 kernel on ``torch.cuda.current_stream()``.
+There is NO fallback: a missing library or a non-GPU tensor raises.  Model code calls these
+through the module (``kernels.attention(...)``).
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libim360_kernels.so")
+_lib = None
+
+_I64, _F32, _INT, _PTR = ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p
+
+_SIGNATURES = {
+    "im360_abi_version": (_INT, []),
+    "im360_last_error": (ctypes.c_char_p, []),
+    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 14 + [_F32, _F32, _INT, _INT, _PTR]),
+    "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
+    "im360_gn_num_slabs": (_I64, [_I64] * 3),
+    "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
+    "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
+    "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 13 + [_INT, _PTR]),
+    "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
+    "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
+    "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR]),
+    "im360_prof_enable": (None, [ctypes.c_uint]),
+    "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
+}
+
+PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libim360_kernels.so (built by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: build it with `make -C imagine360_amd/csrc` "
+                               "(hipcc --offload-arch=gfx950); imagine360_amd has no CPU fallback")
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().im360_last_error().decode()}")
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return 0
+    if t.dtype == torch.float16:
+        return 1
+    raise TypeError(f"imagine360_amd kernels take bfloat16/float16 tensors, got {t.dtype}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("imagine360_amd kernels need tensors on the MI355X (cuda) device; no CPU fallback")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0):
+    """q [B, Nq, heads*d], k/v [B, Nk, heads*d] (last dim contiguous, any row/batch stride),
+    bias [Nq, Nk] shared by every (batch, head).  Returns out [B, Nq, heads*d]."""
+    _dev(q, k, v, bias, out)
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    assert k.shape[0] == B and v.shape[0] == B and v.shape[1] == Nk and k.shape[2] == C and v.shape[2] == C
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    assert out.stride(2) == 1
+    if bias is not None:
+        assert bias.shape == (Nq, Nk) and bias.stride(1) == 1 and bias.dtype == q.dtype
+    if scale is None:
+        scale = d ** -0.5
+    rc = lib().im360_attn_fwd(_p(q), _p(k), _p(v), _p(bias), _p(out), B, heads, Nq, Nk, d,
+                              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                              out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0,
+                              float(scale), float(out_scale), int(accumulate), _dt(q), _stream())
+    _check(rc, "im360_attn_fwd")
+    return out
+
+
+def temporal_attention(qkv, B, F, P, heads):
+    """qkv [B*F*P, 3*C] = fused (q | k | v) projection of token-major activations [B, F, P, C].
+    Attention over the F axis per (batch, pixel, head).  Returns [B*F*P, C]."""
+    _dev(qkv)
+    C = qkv.shape[1] // 3
+    assert qkv.shape[0] == B * F * P and qkv.stride(1) == 1
+    rs = qkv.stride(0)
+    out = torch.empty((B * F * P, C), dtype=qkv.dtype, device=qkv.device)
+    d = C // heads
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    rc = lib().im360_temporal_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, F, P, heads, d,
+                                       P * rs, rs, F * P * rs, P * C, C, F * P * C,
+                                       float(d ** -0.5), _dt(qkv), _stream())
+    _check(rc, "im360_temporal_attn_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ group norm
+def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
+    """x [N, H, W, C] channels-last.  Returns fp32 (scale, shift) [N, C] with GN(x) = x*scale + shift;
+    pad > 0 = statistics of the circularly W-padded tensor."""
+    _dev(x, gamma, beta)
+    N, H, W, C = x.shape
+    assert x.is_contiguous() and gamma.dtype == x.dtype and beta.dtype == x.dtype
+    S = lib().im360_gn_num_slabs(N, H, W)
+    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=x.device)
+    scale = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    shift = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    rc = lib().im360_groupnorm_stats(_p(x), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
+                                     N, H, W, C, groups, pad, float(eps), _dt(x), _stream())
+    _check(rc, "im360_groupnorm_stats")
+    return scale, shift
+
+
+def group_norm_apply(x, scale, shift, silu, pad=0):
+    """y [N, H, W + 2 pad, C] = act(x * scale + shift), circular along W."""
+    _dev(x, scale, shift)
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((N, H, W + 2 * pad, C), dtype=x.dtype, device=x.device)
+    rc = lib().im360_groupnorm_apply(_p(x), _p(scale), _p(shift), _p(y), N, H, W, C, pad, int(bool(silu)),
+                                     _dt(x), _stream())
+    _check(rc, "im360_groupnorm_apply")
+    return y
+
+
+def group_norm(x, gamma, beta, groups, eps, silu=False, pad=0):
+    scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
+    return group_norm_apply(x, scale, shift, silu, pad)
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def pack_conv_weight(w, cin_pad=None):
+    """[Cout, Cin, kh, kw] -> packed [CoutPad128, kh*kw, CinPad32] (zero padded)."""
+    _dev(w)
+    Cout, Cin, kh, kw = w.shape
+    taps = kh * kw
+    assert taps in (1, 9)
+    cin_pad = cin_pad or ((Cin + 31) // 32) * 32
+    cout_pad = ((Cout + 127) // 128) * 128
+    out = torch.empty((cout_pad, taps, cin_pad), dtype=w.dtype, device=w.device)
+    rc = lib().im360_pack_conv_weight(_p(w.contiguous()), _p(out), Cout, Cin, taps, cout_pad, cin_pad, _dt(w), _stream())
+    _check(rc, "im360_pack_conv_weight")
+    return out
+
+
+def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None,
+           temb=None, imgs_per_temb=1, res=None):
+    """x [N, Hin, Win, Cin] -> y [N, Hout, Wout, Cout] (3x3 pad 1 or 1x1, see im360_conv_fwd)."""
+    _dev(x, w_packed, bias, temb, res)
+    N, Hin, Win, Cin = x.shape
+    taps = w_packed.shape[1]
+    assert x.is_contiguous() and w_packed.shape[2] == Cin, (x.shape, w_packed.shape)
+    hc, wc = (2 * Hin, 2 * Win) if up else (Hin, Win)
+    hout = hc // stride
+    if wout is None:
+        wout = wc // stride
+    y = torch.empty((N, hout, wout, cout), dtype=x.dtype, device=x.device)
+    if res is not None:
+        assert res.shape == y.shape and res.is_contiguous()
+    if temb is not None:
+        assert temb.is_contiguous() and temb.shape[1] == cout and temb.shape[0] * imgs_per_temb == N
+    rc = lib().im360_conv_fwd(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
+                              N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off,
+                              imgs_per_temb, _dt(x), _stream())
+    _check(rc, "im360_conv_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------ misc
+def circular_pad_w(x, pad):
+    """x [..., W, C] channels-last -> [..., W + 2 pad, C]."""
+    _dev(x)
+    assert x.is_contiguous()
+    W, C = x.shape[-2], x.shape[-1]
+    rows = x.numel() // (W * C)
+    y = torch.empty(x.shape[:-2] + (W + 2 * pad, C), dtype=x.dtype, device=x.device)
+    rc = lib().im360_circular_pad_w(_p(x), _p(y), rows, W, C, pad, _dt(x), _stream())
+    _check(rc, "im360_circular_pad_w")
+    return y
+
+
+def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv):
+    """x_prev = cx * sample + cv * (uncond + guidance * (cond - uncond))."""
+    _dev(uncond, cond, sample)
+    assert uncond.is_contiguous() and cond.is_contiguous() and sample.is_contiguous()
+    assert uncond.shape == cond.shape == sample.shape and uncond.dtype == sample.dtype
+    out = torch.empty_like(sample)
+    rc = lib().im360_cfg_ddim_update(_p(uncond), _p(cond), _p(sample), _p(out), sample.numel(),
+                                     float(guidance), float(cx), float(cv), _dt(sample), _stream())
+    _check(rc, "im360_cfg_ddim_update")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ profiling
+def prof_enable(kinds):
+    mask = 0
+    for k in kinds:
+        mask |= 1 << PROF_KINDS[k]
+    lib().im360_prof_enable(mask)
+
+
+def prof_collect(kind):
+    ms, n = ctypes.c_double(0.0), ctypes.c_long(0)
+    lib().im360_prof_collect(PROF_KINDS[kind], ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value

@@ -1,0 +1,101 @@
+/* libim360_kernels.so -- C ABI of the MI355X (gfx950) kernels behind imagine360_amd.
+ *
+ * The reference (3DTopia/Imagine360) has no FFI: its arithmetic for this path lives in third-party
+ * wheels (torch ATen / cuDNN, xformers).  Each entry point below therefore cites the reference call
+ * site(s) whose kernel it replaces (paths relative to the reference repository).  Conventions:
+ *   - plain device pointers + int64 sizes/strides (in ELEMENTS), no torch types;
+ *   - dtype: 0 = bfloat16, 1 = float16 (16-bit storage, fp32 accumulation);
+ *   - every function only enqueues work on `stream` (a hipStream_t); no allocation, no sync;
+ *   - returns 0, or a negative code with a message available from im360_last_error().
+ * Activations are channels-last: images [N, H, W, C] where N = (batch x frame), tokens [B, N, C].
+ */
+#ifndef IM360_KERNELS_H
+#define IM360_KERNELS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int im360_abi_version(void);
+const char* im360_last_error(void);
+
+/* softmax(Q K^T * scale + bias) V, head dim D in {32, 64}; head h of batch b lives at
+ * base + b*bs + row*rs + h*D.  bias (optional) is ONE [Nq, Nk] matrix shared by all (b, h).
+ * accumulate != 0: out += out_scale * result (second KV set of the IP cross attention).
+ * Replaces: xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
+ *   diffusers/models/attention_processor.py:1264, 1351, 641 (spatial self / cross attention),
+ *   animatediff/models/attention.py:113-148 (text + IP cross attention),
+ *   src/modules/transformer.py:72 (WarpAttn cross-view attention with additive mask). */
+int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias, void* out,
+                   int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
+                   int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
+                   int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
+                   float scale, float out_scale, int accumulate, int dtype, void* stream);
+
+/* Temporal self-attention over F <= 64 frames on token-major activations [B, F, P, heads*d]
+ * (q, k, v are three views with common strides, e.g. slices of a fused QKV projection).
+ * Replaces: VersatileAttention.forward -> Attention._attention (baddbmm/softmax/bmm) and its
+ *   '(b f) d c <-> (b d) f c' rearranges, animatediff/models/motion_module.py:343-429,
+ *   diffusers/models/attention_processor.py:562-591. */
+int im360_temporal_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                            int64_t B, int64_t F, int64_t P, int64_t heads, int64_t d,
+                            int64_t qkv_fs, int64_t qkv_ps, int64_t qkv_bs,
+                            int64_t o_fs, int64_t o_ps, int64_t o_bs,
+                            float scale, int dtype, void* stream);
+
+/* GroupNorm statistics -> per-(image, channel) fp32 scale/shift such that GN(x) = x*scale + shift.
+ * pad > 0: statistics of the circularly W-padded tensor (the pano branch pads before norm1,
+ * src/models/MVGenModel.py:277-278).  partial: fp32 workspace of N * S * 2 * C floats,
+ * S = im360_gn_num_slabs(N, H, W).
+ * Replaces: nn.GroupNorm / InflatedGroupNorm statistics, animatediff/models/resnet.py:9-17, 224, 236;
+ *   animatediff/models/attention.py:262; motion_module.py:169; unet.py (conv_norm_out); VAE norms. */
+int64_t im360_gn_num_slabs(int64_t N, int64_t H, int64_t W);
+int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, void* partial,
+                          void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C,
+                          int64_t G, int64_t pad, float eps, int dtype, void* stream);
+
+/* y[N, H, W + 2 pad, C] = act(x * scale + shift) with circular W addressing; act 0 = none, 1 = SiLU.
+ * Replaces: the normalise + F.silu pass (resnet.py:224-225, 236-243) fused with pad_pano
+ *   (src/utils/pano.py:75-95). */
+int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
+                          int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
+                          int dtype, void* stream);
+
+/* 3x3 (ntaps = 9) or 1x1 (ntaps = 1) convolution, implicit GEMM on MFMA.  x [N, Hin, Win, Cin],
+ * y [N, Hout, Wout, Cout], w_packed from im360_pack_conv_weight.  stride 1|2; up: input is
+ * nearest-upsampled x2 on the fly; wrap: circular W addressing; x_off: column offset into a
+ * pre-padded input.  Epilogue: + bias[Cout] + temb[n / imgs_per_temb][Cout] + res[N, Hout, Wout, Cout].
+ * Replaces: InflatedConv3d / nn.Conv2d at animatediff/models/resnet.py:19-27, 84, 128, 183, 205, 218,
+ *   227-251; unet.py:134-137, 358; pad_pano/unpad_pano around them (MVGenModel.py:138-143, 276-281,
+ *   305-314, 449-456, 474-478); F.interpolate nearest (resnet.py:104); the VAE convs. */
+int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
+                   const void* res, void* y,
+                   int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                   int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                   int64_t stride, int64_t up, int64_t wrap, int64_t x_off,
+                   int64_t imgs_per_temb, int dtype, void* stream);
+
+/* PyTorch conv weight [Cout, Cin, kh, kw] -> [CoutPad (mult. of 128)][kh*kw][CinPad (mult. of 32)]. */
+int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,
+                           int64_t CoutPad, int64_t CinPad, int dtype, void* stream);
+
+/* x [rows, W, C] -> y [rows, W + 2 pad, C], circular along W.
+ * Replaces: pad_pano on the latent before VAE decode, pipeline_animation_inference_dual.py:813. */
+int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
+                         int dtype, void* stream);
+
+/* out = cx * x + cv * (uncond + guidance * (cond - uncond)); cx, cv = DDIM v-prediction coefficients.
+ * Replaces: the CFG combine + DDIMScheduler.step elementwise chain,
+ *   pipeline_animation_inference_dual.py:791-800; diffusers/schedulers/scheduling_ddim.py:300-350. */
+int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
+                          float guidance, float cx, float cv, int dtype, void* stream);
+
+/* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
+ * 3 gn_stats, 4 gn_apply).  collect() synchronises on the recorded events. */
+void im360_prof_enable(unsigned mask);
+int im360_prof_collect(int kind, double* total_ms, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle / plain fp32 torch on the
+same seeded inputs.  Tolerances are for 16-bit storage with fp32 accumulation: relative L2 error of
+the whole tensor <= 1e-2 (bf16) / 3e-3 (fp16) unless noted, plus a loose max-abs bound."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from im360_oracle import geometry as OG, unet as OU  # noqa: E402
+from imagine360_amd import kernels as K  # noqa: E402
+
+DTYPES = [torch.bfloat16, torch.float16]
+TOL = {torch.bfloat16: 1e-2, torch.float16: 3e-3}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q16(t, dt):
+    """Round to the 16-bit dtype and back so the reference sees exactly the kernel's inputs."""
+    return t.to(dt).float()
+
+
+def test_library_loads():
+    assert K.lib().im360_abi_version() == 1
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 256, 192, 64), (3, 2, 100, 77, 64), (2, 5, 16, 16, 64),
+                                          (1, 4, 640, 1280, 32), (2, 2, 33, 130, 32), (1, 1, 2048, 2048, 64)])
+def test_attention(dt, B, H, Nq, Nk, D):
+    q, k, v = (q16(rnd(B, n, H * D, seed=s), dt) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    ref = OU.sdpa(q, k, v, H)
+    out = K.attention(q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda(), H)
+    assert rel(out, ref) < TOL[dt]
+    assert (out.float().cpu() - ref).abs().max() < 0.05
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_bias_and_strided_qkv(dt):
+    """WarpAttn form: fused QKV rows (row stride 3C), shared [Nq, Nk] bias in [-1, 1], d = 32."""
+    B, H, D, Nq, Nk = 3, 4, 32, 200, 320
+    C = H * D
+    qkv_q = q16(rnd(B, Nq, 3 * C, seed=4), dt)
+    qkv_k = q16(rnd(B, Nk, 3 * C, seed=5), dt)
+    bias = q16(torch.rand(Nq, Nk, generator=torch.Generator().manual_seed(6)) * 2 - 1, dt)
+    ref = OU.sdpa(qkv_q[..., :C], qkv_k[..., C:2 * C], qkv_k[..., 2 * C:], H, bias=bias)
+    dq, dk = qkv_q.to(dt).cuda(), qkv_k.to(dt).cuda()
+    out = K.attention(dq[..., :C], dk[..., C:2 * C], dk[..., 2 * C:], H, bias=bias.to(dt).cuda())
+    assert rel(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_two_kv_sets_accumulate(dt):
+    """IP cross attention: attn(Q, K_text, V_text) + 1.0 * attn(Q, K_ip, V_ip), logit scale 1.0 or d^-1/2."""
+    B, H, D, Nq = 2, 5, 64, 300
+    C = H * D
+    q = q16(rnd(B, Nq, C, seed=7, scale=0.3), dt)
+    k1, v1, k2, v2 = (q16(rnd(B, n, C, seed=s), dt) for n, s in ((77, 8), (77, 9), (64, 10), (64, 11)))
+    for scale in (1.0, D ** -0.5):
+        ref = OU.sdpa(q, k1, v1, H, scale=scale) + OU.sdpa(q, k2, v2, H, scale=scale)
+        dq = q.to(dt).cuda()
+        out = K.attention(dq, k1.to(dt).cuda(), v1.to(dt).cuda(), H, scale=scale)
+        K.attention(dq, k2.to(dt).cuda(), v2.to(dt).cuda(), H, scale=scale, out=out, accumulate=True)
+        assert rel(out, ref) < 1.5 * TOL[dt]
+
+
+def test_attention_softmax_rescale_branch():
+    """Force the running max to jump in a late KV tile (spiked key) -- the online-softmax rescale path."""
+    dt = torch.bfloat16
+    B, H, D, Nq, Nk = 1, 1, 64, 64, 512
+    q, k, v = (q16(rnd(B, n, D, seed=s), dt) for n, s in ((Nq, 12), (Nk, 13), (Nk, 14)))
+    k[0, 300] = q[0, 5] * 6.0
+    k[0, 450] = q[0, 9] * 9.0
+    ref = OU.sdpa(q, k, v, H)
+    out = K.attention(q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda(), H)
+    assert rel(out, ref) < TOL[dt]
+    assert (out.float().cpu() - ref)[0, [5, 9]].abs().max() < 0.05
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,Fr,P,heads,d", [(2, 16, 96, 8, 40), (3, 8, 33, 8, 8), (1, 48, 20, 8, 16), (2, 16, 7, 8, 160)])
+def test_temporal_attention(dt, B, Fr, P, heads, d):
+    C = heads * d
+    qkv = q16(rnd(B * Fr * P, 3 * C, seed=15), dt)
+    t = qkv.reshape(B, Fr, P, 3 * C).permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)      # (b d) f c
+    ref = OU.sdpa(t[..., :C], t[..., C:2 * C], t[..., 2 * C:], heads)
+    ref = ref.reshape(B, P, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * P, C)
+    out = K.temporal_attention(qkv.to(dt).cuda(), B, Fr, P, heads)
+    assert rel(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C,pad,silu", [(3, 8, 16, 64, 0, True), (2, 16, 32, 320, 2, True), (5, 4, 4, 1280, 0, False),
+                                                (2, 6, 10, 2560, 2, True), (1, 64, 128, 320, 2, True)])
+def test_group_norm(dt, N, H, W, C, pad, silu):
+    x = q16(rnd(N, H, W, C, seed=16) + 0.5, dt)
+    gamma, beta = q16(1 + 0.1 * rnd(C, seed=17), dt), q16(0.1 * rnd(C, seed=18), dt)
+    xr = OG.pad_pano(x.permute(0, 3, 1, 2), pad)
+    ref = F.group_norm(xr, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    out = K.group_norm(x.to(dt).cuda(), gamma.to(dt).cuda(), beta.to(dt).cuda(), 32, 1e-5, silu=silu, pad=pad)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < TOL[dt]
+
+
+def _conv_ref(x, w, b, stride=1, up=False, wrap_pad=0, unpad=0):
+    xr = x.permute(0, 3, 1, 2)
+    if wrap_pad:
+        xr = OG.pad_pano(xr, wrap_pad)
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(xr, w, b, stride=stride, padding=w.shape[-1] // 2)
+    return OG.unpad_pano(y, unpad).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (3, 8, 12, 320, 640), (5, 4, 4, 256, 128), (1, 32, 64, 32, 4),
+                                             (2, 9, 7, 96, 200)])
+def test_conv3x3_plain(dt, N, H, W, Cin, Cout):
+    x = q16(rnd(N, H, W, Cin, seed=19), dt)
+    w = q16(rnd(Cout, Cin, 3, 3, seed=20, scale=(9 * Cin) ** -0.5), dt)
+    b = q16(rnd(Cout, seed=21, scale=0.1), dt)
+    ref = _conv_ref(x, w, b)
+    wp = K.pack_conv_weight(w.to(dt).cuda())
+    out = K.conv2d(x.to(dt).cuda(), wp, Cout, bias=b.to(dt).cuda())
+    assert rel(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_variants_pano(dt):
+    """The pano-branch addressing modes against pad_pano -> conv -> unpad_pano of the reference."""
+    N, H, W, C, Co = 2, 8, 16, 64, 96
+    x = q16(rnd(N, H, W, C, seed=22), dt)
+    w = q16(rnd(Co, C, 3, 3, seed=23, scale=(9 * C) ** -0.5), dt)
+    b = q16(rnd(Co, seed=24, scale=0.1), dt)
+    dx, db = x.to(dt).cuda(), b.to(dt).cuda()
+    wp = K.pack_conv_weight(w.to(dt).cuda())
+    # conv_in / conv_out: pad 1 -> conv -> unpad 1  == circular conv
+    assert rel(K.conv2d(dx, wp, Co, bias=db, wrap=True), _conv_ref(x, w, b, wrap_pad=1, unpad=1)) < TOL[dt]
+    # downsampler: pad 2 -> conv stride 2 -> unpad 1
+    assert rel(K.conv2d(dx, wp, Co, bias=db, wrap=True, stride=2), _conv_ref(x, w, b, stride=2, wrap_pad=2, unpad=1)) < TOL[dt]
+    assert rel(K.conv2d(dx, wp, Co, bias=db, stride=2), _conv_ref(x, w, b, stride=2)) < TOL[dt]
+    # upsampler: pad 1 -> nearest x2 -> conv -> unpad 2
+    assert rel(K.conv2d(dx, wp, Co, bias=db, wrap=True, up=True), _conv_ref(x, w, b, up=True, wrap_pad=1, unpad=2)) < TOL[dt]
+    assert rel(K.conv2d(dx, wp, Co, bias=db, up=True), _conv_ref(x, w, b, up=True)) < TOL[dt]
+    # resnet conv2 on the pre-padded tensor: read columns 2 .. W+1 of a W+4 wide input
+    xp = OG.pad_pano(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+    ref = OG.unpad_pano(F.conv2d(xp.permute(0, 3, 1, 2), w, b, padding=1), 2).permute(0, 2, 3, 1)
+    assert rel(K.conv2d(xp.to(dt).cuda(), wp, Co, bias=db, x_off=2, wout=W), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_epilogue_temb_residual_and_1x1(dt):
+    N, Fr, H, W, C, Co = 6, 3, 8, 8, 128, 64
+    x = q16(rnd(N, H, W, C, seed=25), dt)
+    w = q16(rnd(Co, C, 3, 3, seed=26, scale=(9 * C) ** -0.5), dt)
+    w1 = q16(rnd(Co, C, 1, 1, seed=27, scale=C ** -0.5), dt)
+    b = q16(rnd(Co, seed=28, scale=0.1), dt)
+    temb = q16(rnd(N // Fr, Co, seed=29), dt)
+    res = _conv_ref(x, w1, b)                      # 1x1 shortcut
+    short = K.conv2d(x.to(dt).cuda(), K.pack_conv_weight(w1.to(dt).cuda()), Co, bias=b.to(dt).cuda())
+    assert rel(short, res) < TOL[dt]
+    ref = _conv_ref(x, w, b) + temb.repeat_interleave(Fr, 0)[:, None, None, :] + q16(res, dt)
+    out = K.conv2d(x.to(dt).cuda(), K.pack_conv_weight(w.to(dt).cuda()), Co, bias=b.to(dt).cuda(),
+                   temb=temb.to(dt).cuda(), imgs_per_temb=Fr, res=q16(res, dt).to(dt).cuda())
+    assert rel(out, ref) < TOL[dt]
+
+
+def test_circular_pad_and_cfg_ddim():
+    dt = torch.bfloat16
+    x = q16(rnd(3, 5, 16, 8, seed=30), dt)
+    ref = OG.pad_pano(x.permute(0, 1, 3, 2), 4).permute(0, 1, 3, 2)
+    assert torch.equal(K.circular_pad_w(x.to(dt).cuda(), 4).float().cpu(), ref)      # pure copy: bit exact
+    u, c, s = (q16(rnd(1, 4, 16, 8, 16, seed=i), dt) for i in (31, 32, 33))
+    g, cx, cv = 7.5, 0.83, -0.41
+    ref = cx * s + cv * (u + g * (c - u))
+    out = K.cfg_ddim_update(u.to(dt).cuda(), c.to(dt).cuda(), s.to(dt).cuda(), g, cx, cv)
+    assert rel(out, ref) < TOL[dt]
+
+
+def test_bad_arguments_fail_loudly():
+    x = torch.zeros(1, 16, 40, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="head dim"):
+        K.attention(x, x, x, heads=1)                 # d = 40 unsupported by attn_fwd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        K.attention(x.cpu(), x.cpu(), x.cpu(), heads=1)
+    with pytest.raises(TypeError):
+        K.group_norm(torch.zeros(1, 2, 2, 32, device="cuda"), torch.ones(32, device="cuda"), torch.zeros(32, device="cuda"), 32, 1e-5)
