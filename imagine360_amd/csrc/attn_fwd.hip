@@ -23,6 +23,7 @@ namespace im360 {
 struct AttnParams {
     const void* q; const void* k; const void* v; const void* bias; void* out;
     int B, H, Nq, Nk;
+    int kv_group;        // K/V batch index = query batch index / kv_group (context shared by the frames of a video)
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, bias_rs;   // element strides
     float scale_log2;    // logit scale * log2(e)
     float out_scale;     // multiplies the normalised result
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     const int q0 = blockIdx.y * (32 * NW) + wid * 32;
 
     const T* qb = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
-    const T* kb_ = (const T*)p.k + (long)b * p.k_bs + (long)h * D;
-    const T* vb = (const T*)p.v + (long)b * p.v_bs + (long)h * D;
+    const T* kb_ = (const T*)p.k + (long)(b / p.kv_group) * p.k_bs + (long)h * D;
+    const T* vb = (const T*)p.v + (long)(b / p.kv_group) * p.v_bs + (long)h * D;
     const T* bias = (const T*)p.bias;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 dc + 8 hi .. +7]
@@ -262,11 +263,12 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
                               int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                               int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
-                              float scale, float out_scale, int accumulate, int dtype, void* stream) {
+                              int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
     IM360_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attn_fwd: empty problem B=%ld H=%ld Nq=%ld Nk=%ld",
                     (long)B, (long)H, (long)Nq, (long)Nk);
+    IM360_CHECK_ARG(kv_group >= 1, "attn_fwd: kv_group must be >= 1");
     IM360_CHECK_ARG(D == 32 || D == 64, "attn_fwd: head dim %ld unsupported (32, 64)", (long)D);
     IM360_CHECK_ARG(B * H <= 0x7fffffffL, "attn_fwd: B*H too large");
     IM360_CHECK_ARG((q_rs % 8) == 0 && (k_rs % 8) == 0 && (v_rs % 8) == 0 && (o_rs % 4) == 0 &&
@@ -280,7 +282,7 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     }
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.out = out;
-    p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk;
+    p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;
     p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = accumulate;

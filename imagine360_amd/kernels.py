@@ -17,7 +17,7 @@ _I64, _F32, _INT, _PTR = ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_
 _SIGNATURES = {
     "im360_abi_version": (_INT, []),
     "im360_last_error": (ctypes.c_char_p, []),
-    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 14 + [_F32, _F32, _INT, _INT, _PTR]),
+    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR]),
     "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
@@ -81,14 +81,14 @@ def _p(t):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0):
-    """q [B, Nq, heads*d], k/v [B, Nk, heads*d] (last dim contiguous, any row/batch stride),
+def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1):
+    """q [B, Nq, heads*d], k/v [B / kv_group, Nk, heads*d] (last dim contiguous, any row/batch stride),
     bias [Nq, Nk] shared by every (batch, head).  Returns out [B, Nq, heads*d]."""
     _dev(q, k, v, bias, out)
     B, Nq, C = q.shape
     Nk = k.shape[1]
     d = C // heads
-    assert k.shape[0] == B and v.shape[0] == B and v.shape[1] == Nk and k.shape[2] == C and v.shape[2] == C
+    assert k.shape[0] * kv_group == B and v.shape[0] == k.shape[0] and v.shape[1] == Nk and k.shape[2] == C and v.shape[2] == C
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     if out is None:
         assert not accumulate
@@ -100,7 +100,7 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
         scale = d ** -0.5
     rc = lib().im360_attn_fwd(_p(q), _p(k), _p(v), _p(bias), _p(out), B, heads, Nq, Nk, d,
                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                              out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0,
+                              out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0, kv_group,
                               float(scale), float(out_scale), int(accumulate), _dt(q), _stream())
     _check(rc, "im360_attn_fwd")
     return out

@@ -1,0 +1,162 @@
+"""Channels-last building blocks shared by the UNet, the cross-view blocks and the VAE.
+
+Internal activation layout ("CL"): images ``[N, H, W, C]`` with ``N = batch * frames`` (batch-major),
+i.e. token-major ``[N, H*W, C]`` for free.  Public ``forward`` methods of the mirrored reference
+classes take/return the reference layout ``[b, c, f, h, w]``; ``forward_cl`` methods are the fast
+internal path.  All arithmetic-heavy work goes through ``imagine360_amd.kernels`` (HIP); GEMM-shaped
+Linear layers use torch (hipBLASLt), as SURVEY.md section 2b allows.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels
+
+
+def to_cl(x5):
+    """[b, c, f, h, w] -> ([b*f, h, w, c] contiguous, f)."""
+    b, c, f, h, w = x5.shape
+    return x5.permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c).contiguous(), f
+
+
+def from_cl(x, f):
+    """[b*f, h, w, c] -> [b, c, f, h, w]."""
+    n, h, w, c = x.shape
+    return x.reshape(n // f, f, h, w, c).permute(0, 4, 1, 2, 3)
+
+
+class DerivedCache:
+    """Tensors derived from parameters (packed conv weights, fused QKV matrices), rebuilt whenever a
+    source parameter is modified in place (``_version``) or replaced (``data_ptr``) -- e.g. by
+    ``load_state_dict`` or the LoRA merge of inference_dual_p2e.py:175-195."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, build):
+        sig = tuple((p.data_ptr(), p._version, p.dtype, p.device, tuple(p.shape), p.stride()) for p in params if p is not None)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, build())
+            self._store[key] = hit
+        return hit[1]
+
+
+class InflatedConv3d(nn.Conv2d):
+    """Per-frame 2-D convolution (animatediff/models/resnet.py:19-27) on the HIP implicit-GEMM kernel.
+    Parameters keep nn.Conv2d's names/shapes so reference checkpoints load unchanged."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._derived = DerivedCache()
+
+    def packed_weight(self):
+        cin = self.in_channels
+        cin_pad = ((cin + 31) // 32) * 32
+        return self._derived.get("w", (self.weight,), lambda: kernels.pack_conv_weight(self.weight, cin_pad))
+
+    @property
+    def cin_padded(self):
+        return ((self.in_channels + 31) // 32) * 32
+
+    def forward_cl(self, x, wrap=False, up=False, x_off=0, wout=None, temb=None, imgs_per_temb=1, res=None):
+        """x [N, H, W, Cin(+zero pad to a multiple of 32)] channels-last."""
+        if x.shape[-1] != self.cin_padded:
+            x = F.pad(x, (0, self.cin_padded - x.shape[-1]))
+        return kernels.conv2d(x, self.packed_weight(), self.out_channels, bias=self.bias, stride=self.stride[0],
+                              up=up, wrap=wrap, x_off=x_off, wout=wout, temb=temb, imgs_per_temb=imgs_per_temb,
+                              res=res)
+
+    def forward(self, x):
+        if x.dim() == 5:
+            xc, f = to_cl(x)
+            return from_cl(self.forward_cl(xc), f)
+        return self.forward_cl(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+
+
+class InflatedGroupNorm(nn.GroupNorm):
+    """Per-frame GroupNorm (animatediff/models/resnet.py:9-17) on the HIP stats/apply kernels."""
+
+    def stats_cl(self, x, pad=0):
+        return kernels.group_norm_stats(x, self.weight, self.bias, self.num_groups, self.eps, pad)
+
+    def forward_cl(self, x, silu=False, pad=0):
+        scale, shift = self.stats_cl(x, pad)
+        return kernels.group_norm_apply(x, scale, shift, silu, pad)
+
+    def forward(self, x):
+        if x.dim() == 5:
+            xc, f = to_cl(x)
+            return from_cl(self.forward_cl(xc), f)
+        return self.forward_cl(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+
+
+class GEGLU(nn.Module):
+    """x -> a * gelu(gate), (a | gate) = proj(x)  (diffusers/models/activations.py:93-125)."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        h = self.proj(x)
+        a, gate = h.chunk(2, dim=-1)
+        return a * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    """GEGLU feed-forward with the reference's parameter names ``net.0.proj`` / ``net.2``
+    (diffusers/models/attention_lora.py:493-547; src/modules/transformer.py:20-40)."""
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class QKVAttention(nn.Module):
+    """Attention projections with the reference's parameter names (``to_q`` / ``to_k`` / ``to_v`` /
+    ``to_out.0``; diffusers/models/attention_processor.py:38-215).  Self-attention runs one fused QKV
+    GEMM and hands strided views to the HIP flash-attention kernel."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, bias=False, out_list=True):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head, self.inner_dim = heads, dim_head, inner
+        ctx = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(ctx, inner, bias=bias)
+        self.to_v = nn.Linear(ctx, inner, bias=bias)
+        if out_list:
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
+        else:
+            self.to_out = nn.Linear(inner, query_dim)
+        self._derived = DerivedCache()
+        self._use_memory_efficient_attention_xformers = False
+
+    def out_proj(self, x):
+        return self.to_out[0](x) if isinstance(self.to_out, nn.ModuleList) else self.to_out(x)
+
+    def fused_qkv_weight(self):
+        ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        return self._derived.get("qkv", ps, lambda: torch.cat([p.detach() for p in ps], dim=0).contiguous())
+
+    def qkv(self, x):
+        """x [..., C] -> fused [..., 3*inner] (valid when to_q/k/v share their input)."""
+        return F.linear(x, self.fused_qkv_weight())
+
+    def self_attention(self, x, bias=None):
+        """x [B, N, C] -> attention output before the out projection."""
+        qkv = self.qkv(x)
+        c = self.inner_dim
+        return kernels.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, bias=bias)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
+        if encoder_hidden_states is None:
+            return self.out_proj(self.self_attention(hidden_states))
+        q = self.to_q(hidden_states)
+        k, v = self.to_k(encoder_hidden_states), self.to_v(encoder_hidden_states)
+        return self.out_proj(kernels.attention(q, k, v, self.heads))

@@ -1,0 +1,243 @@
+"""Dual-branch coupled model: MultiViewBaseModel + WarpAttn (src/models/MVGenModel.py:16-481,
+src/modules/attn_perspano.py:10-99, src/modules/transformer.py:43-206), channels-last on HIP kernels.
+
+What changed relative to the reference, deliberately:
+  * masks / spherical coordinates / positional encodings are step-invariant: built once per resolution
+    (both the normal and the antipodal variant) and cached on the device; per call only the reference's
+    ``random.random() < 0.4`` coin is drawn, so Python-RNG parity holds;
+  * both WarpAttn directions share LN(x + pe) of each side and one fused QKV GEMM per side;
+  * the IP-adapter conditioning (TemporalProjection + Resampler) is hoisted out of the loop; the
+    per-step ``randn_like`` noise (MVGenModel.py:186-187) is still drawn every call, pano first;
+  * no empty_cache()/flush() syncs, no circular-pad copies (folded into the kernels, ``pano=True``).
+"""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels
+from . import pano_geometry as G
+from .layers import DerivedCache, FeedForward, QKVAttention, to_cl
+
+
+class SphericalPE(nn.Module):
+    """[sin(lon f), sin(lat f), cos(lon f), cos(lat f)], f = base^k (transformer.py:170-206).  Evaluated
+    in fp32 exactly as the reference's CPU path does (the top frequency at C=320 is 2^79, so a 16-bit
+    evaluation is numerically arbitrary -- SURVEY.md section 7) and cast afterwards."""
+
+    def __init__(self, N_freqs, logscale=True):
+        super().__init__()
+        self.N_freqs = N_freqs
+        base = 2 if N_freqs <= 80 else 5000 ** (1 / (N_freqs / 2.5))
+        self.register_buffer("freq_bands", base ** torch.linspace(0, N_freqs - 1, N_freqs))
+
+    def forward(self, coords):
+        shape = coords.shape[:-1]
+        base = 2 if self.N_freqs <= 80 else 5000 ** (1 / (self.N_freqs / 2.5))
+        freq = base ** torch.linspace(0, self.N_freqs - 1, self.N_freqs, device=coords.device)   # fp32, not the (castable) buffer
+        # evaluated on the host: sin/cos of arguments up to 2^79 * pi only reproduce the CPU reference when
+        # the same libm is used; this runs once per resolution (WarpAttn caches the result)
+        freq = freq.cpu()
+        enc = coords.float().cpu().reshape(-1, 2, 1) * freq
+        return torch.cat([enc.sin(), enc.cos()], dim=1).reshape(*shape, -1).to(coords.device)
+
+
+class _CrossViewBlock(nn.Module):
+    """src/modules/transformer.py:135-167 with its parameter names (attn1.to_q/to_k/to_v/to_out, ff, norm1, norm2);
+    the output projections are zero-initialised like the reference (transformer.py:30-32, 55-57)."""
+
+    def __init__(self, dim, n_heads, d_head):
+        super().__init__()
+        self.attn1 = QKVAttention(dim, dim, n_heads, d_head, out_list=False)
+        self.ff = FeedForward(dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        for p in (self.attn1.to_out.weight, self.attn1.to_out.bias, self.ff.net[2].weight, self.ff.net[2].bias):
+            nn.init.zeros_(p)
+
+
+class WarpAttn(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.transformer = _CrossViewBlock(dim, dim // 32, 32)
+        self.mv_attn = _CrossViewBlock(dim, dim // 32, 32)        # present in reference checkpoints, never used
+        self.pe = SphericalPE(dim // 4)
+        self.dim = dim
+        self._geom = {}
+
+    def geometry(self, ph, pw, eh, ew, cameras, opposite, device, dtype):
+        fov, theta, phi = G.camera_lists(cameras)
+        key = (ph, pw, eh, ew, bool(opposite), str(device), dtype, tuple(fov), tuple(theta), tuple(phi))
+        if key not in self._geom:
+            with torch.no_grad():
+                b_e2p, b_p2e = G.cross_view_bias(ph, pw, eh, ew, cameras, opposite, device)
+                pc, ec = G.spherical_coords(ph, pw, eh, ew, cameras)
+                pers_pe = self.pe(pc.to(device)).reshape(-1, self.dim)          # (m h w) c
+                equi_pe = self.pe(ec.to(device)).reshape(-1, self.dim)          # (h w) c
+                self._geom[key] = (b_e2p.to(dtype), b_p2e.to(dtype), pers_pe.to(dtype), equi_pe.to(dtype))
+        return self._geom[key]
+
+    def forward_cl(self, pers, equi, cameras, frames, opposite=None):
+        """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes."""
+        t = self.transformer
+        nf, ph, pw, c = pers.shape
+        ne_img, eh, ew, _ = equi.shape
+        b = ne_img // frames
+        m = nf // ne_img
+        if opposite is None:
+            opposite = random.random() < 0.4                     # the reference's coin, one draw per call
+        b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
+        eq = equi.reshape(b * frames, eh * ew, c)
+        # (b m) f (h w) c -> (b f) (m h w) c
+        pr = pers.reshape(b, m, frames, ph * pw, c).permute(0, 2, 1, 3, 4).reshape(b * frames, m * ph * pw, c)
+        eq_n = t.norm1(eq + equi_pe)
+        pr_n = t.norm1(pr + pers_pe)
+        qkv_e, qkv_p = t.attn1.qkv(eq_n), t.attn1.qkv(pr_n)
+        h = t.attn1.heads
+        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p)
+        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e)
+        eq = t.attn1.to_out(a_e) + eq
+        eq = t.ff(t.norm2(eq)) + eq
+        pr = t.attn1.to_out(a_p) + pr
+        pr = t.ff(t.norm2(pr)) + pr
+        pers_out = pr.reshape(b, frames, m, ph, pw, c).permute(0, 2, 1, 3, 4, 5).reshape(nf, ph, pw, c)
+        return pers_out.contiguous(), eq.reshape(ne_img, eh, ew, c)
+
+    def forward(self, pers_x, equi_x, cameras):
+        p, f = to_cl(pers_x)
+        e, _ = to_cl(equi_x)
+        po, eo = self.forward_cl(p, e, cameras, f)
+        from .layers import from_cl
+        return from_cl(po, f), from_cl(eo, f)
+
+
+class MultiViewBaseModel(nn.Module):
+    """Interleaved block-by-block forward of the perspective and panorama UNets with 7 WarpAttn
+    (src/models/MVGenModel.py:16-481)."""
+
+    def __init__(self, unet, pano_unet, pano_pad=True, device="cuda"):
+        super().__init__()
+        self.unet, self.pano_unet, self.pano_pad = unet, pano_unet, pano_pad
+        self.cp_blocks_encoder = nn.ModuleList([WarpAttn(blk.downsamplers[-1].out_channels)
+                                                for blk in unet.down_blocks if blk.downsamplers is not None])
+        self.cp_blocks_mid = WarpAttn(unet.mid_block.resnets[-1].out_channels)
+        self.cp_blocks_decoder = nn.ModuleList([WarpAttn(blk.upsamplers[0].channels)
+                                                for blk in unet.up_blocks if blk.upsamplers is not None])
+        self.trainable_parameters = [(list(self.cp_blocks_mid.parameters()) + list(self.cp_blocks_decoder.parameters())
+                                      + list(self.cp_blocks_encoder.parameters()), 1.0)]
+        self.noise_on_host = False      # True: draw the per-step IP noise from the CPU generator (CPU-reference RNG parity)
+        self.taps = None                # dict -> records (pers, equi) after each WarpAttn, for tests
+        self._rig_cache = {}
+
+    def _rig(self, cameras, m):
+        """Camera dict flattened to [m, ...] plus host-side FoV/theta/phi lists, cached so a denoising loop
+        does not sync on the (device-resident) camera tensors every step."""
+        th = cameras["theta"]
+        key = (th.data_ptr(), th._version, m) if torch.is_tensor(th) else (id(th), 0, m)
+        hit = self._rig_cache.get(key)
+        if hit is None:
+            cams = {k: (v.reshape(-1, *v.shape[2:])[:m] if torch.is_tensor(v) and v.dim() >= 2 else v)
+                    for k, v in cameras.items()}
+            cams["_lists"] = G.camera_lists(cams)
+            self._rig_cache = {key: cams}
+            hit = cams
+        return hit
+
+    def _ip_noise(self, like):
+        if self.noise_on_host:
+            return torch.randn(like.shape, dtype=torch.float32).to(device=like.device, dtype=like.dtype)
+        return torch.randn_like(like)
+
+    def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras, use_fps_condition,
+                use_ip_plus_cross_attention, fps_tensor_pano, fps_tensor_pers, reference_images_clip_feat_pano,
+                reference_images_clip_feat_pers, relative_position_tensor, pitchs_tensor):
+        if not use_ip_plus_cross_attention:
+            raise NotImplementedError("the reference forward cannot run without use_ip_plus_cross_attention "
+                                      "(MVGenModel.py:245-246 never binds the encoder states)")
+        un, pu = self.unet, self.pano_unet
+        dt = un.dtype
+        b, m, c, f, h, w = latents.shape
+        cams = self._rig(cameras, m)
+        # ---- time / fps embeddings (MVGenModel.py:104-133)
+        ts = timestep.reshape(-1)[:1]
+        fps_pers = fps_tensor_pers.reshape(-1).expand(b * m) if use_fps_condition else None
+        fps_pano = fps_tensor_pano.reshape(-1).expand(b) if use_fps_condition else None
+        emb = un.time_embed(ts.expand(b * m), fps_pers)
+        pemb = pu.time_embed(ts.expand(b), fps_pano)
+        # ---- inputs to channels-last, channel-padded for the MFMA conv
+        x = latents.to(dt).permute(0, 1, 3, 4, 5, 2).reshape(b * m * f, h, w, c)
+        px = pano_latent.to(dt).permute(0, 2, 3, 4, 1).reshape(b * f, *pano_latent.shape[3:], c)
+        x = un.conv_in_cl(x.contiguous())
+        px = pu.conv_in_cl(px.contiguous(), pano=self.pano_pad)
+        # ---- IP-adapter conditioning (MVGenModel.py:155-246)
+        feat_pers = reference_images_clip_feat_pers
+        ip_pano = pu.ip_tokens_clean(reference_images_clip_feat_pano)
+        if feat_pers.stride(1) == 0 or m == 1:       # one feature tensor shared by all views (pipeline :713)
+            ip_pers = un.ip_tokens_clean(feat_pers[:, 0]).repeat_interleave(m, dim=0)
+        else:
+            ip_pers = un.ip_tokens_clean(feat_pers.reshape(b * m, *feat_pers.shape[2:]))
+        ip_pano = ip_pano + self._ip_noise(ip_pano) * 0.1
+        ip_pers = ip_pers + self._ip_noise(ip_pers) * 0.1
+        if relative_position_tensor is not None and pu.use_relative_postions == "WithAdapter":
+            ip_pano = ip_pano + pu.relpos_tokens(relative_position_tensor, pitchs_tensor, ip_pano.shape[1])
+        pctx = torch.cat([pano_prompt_embd.to(dt), ip_pano], dim=1)
+        ctx = torch.cat([prompt_embd.to(dt), ip_pers], dim=1)
+
+        pano = self.pano_pad
+        taps = self.taps
+
+        def warp(blk, name, a, e):
+            a, e = blk.forward_cl(a, e, cams, f)
+            if taps is not None:
+                taps[name] = (a, e)
+            return a, e
+
+        # ---- down (MVGenModel.py:261-326)
+        skips, pskips = [x], [px]
+        for i, (db, pdb) in enumerate(zip(un.down_blocks, pu.down_blocks)):
+            for j in range(len(db.resnets)):
+                x = db.resnets[j].forward_cl(x, emb, f)
+                px = pdb.resnets[j].forward_cl(px, pemb, f, pano)
+                if db.has_cross_attention:           # DownBlock3D's motion modules are skipped (:292-303)
+                    x = db.attentions[j].forward_cl(x, ctx, f)
+                    if db.motion_modules[j] is not None:
+                        x = db.motion_modules[j].forward_cl(x, f)
+                    px = pdb.attentions[j].forward_cl(px, pctx, f)
+                    if pdb.motion_modules[j] is not None:
+                        px = pdb.motion_modules[j].forward_cl(px, f)
+                skips.append(x)
+                pskips.append(px)
+            if db.downsamplers is not None:
+                x = db.downsamplers[0].forward_cl(x)
+                px = pdb.downsamplers[0].forward_cl(px, pano)
+                skips.append(x)
+                pskips.append(px)
+                x, px = warp(self.cp_blocks_encoder[i], f"enc{i}", x, px)
+        # ---- mid (:336-380)
+        x = un.mid_block.forward_cl(x, emb, ctx, f)
+        px = pu.mid_block.forward_cl(px, pemb, pctx, f, pano)
+        x, px = warp(self.cp_blocks_mid, "mid", x, px)
+        # ---- up (:395-458)
+        for i, (ub, pub) in enumerate(zip(un.up_blocks, pu.up_blocks)):
+            for j in range(len(ub.resnets)):
+                x = ub.resnets[j].forward_cl(torch.cat([x, skips.pop()], dim=-1), emb, f)
+                px = pub.resnets[j].forward_cl(torch.cat([px, pskips.pop()], dim=-1), pemb, f, pano)
+                if ub.has_cross_attention:           # UpBlock3D's motion modules are skipped (:426-443)
+                    x = ub.attentions[j].forward_cl(x, ctx, f)
+                    if ub.motion_modules[j] is not None:
+                        x = ub.motion_modules[j].forward_cl(x, f)
+                    px = pub.attentions[j].forward_cl(px, pctx, f)
+                    if pub.motion_modules[j] is not None:
+                        px = pub.motion_modules[j].forward_cl(px, f)
+            if ub.upsamplers is not None:
+                x, px = warp(self.cp_blocks_decoder[i], f"dec{i}", x, px)
+                x = ub.upsamplers[0].forward_cl(x)
+                px = pub.upsamplers[0].forward_cl(px, pano)
+        # ---- out (:462-479)
+        x = un.conv_out_cl(x)
+        px = pu.conv_out_cl(px, pano)
+        co = x.shape[-1]
+        sample = x.reshape(b, m, f, h, w, co).permute(0, 1, 5, 2, 3, 4)
+        pano_sample = px.reshape(b, f, *px.shape[1:3], co).permute(0, 4, 1, 2, 3)
+        return sample, pano_sample

@@ -1,0 +1,208 @@
+"""Equirectangular <-> perspective geometry of the cross-view attention, computed once per
+(resolution, camera rig) and cached on the device.
+
+The reference rebuilds all of this on every WarpAttn call -- 7x per denoising step -- through dense
+one-hot images of shape (views, pixels, H, W) pushed through kornia ``remap``
+(src/utils/utils.py:12-164; src/utils/Perspective_and_Equirectangular/{e2p,p2e}.py).  A remapped
+one-hot image is just the bilinear footprint of one sample point, so here the footprints are scattered
+directly into the (views, equi-pixel, pers-pixel) correspondence matrix: same numbers, no 20 x N^2
+intermediates, and the result is step-invariant so it is built once.  Only the reference's
+``random.random() < 0.4`` coin (utils.py:15) stays per call.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------- reference API helpers
+def pad_pano(pano, padding):
+    """Circular pad of the last axis of a (b c h w) / (b m c h w) / (b c f h w) tensor (src/utils/pano.py:75-95)."""
+    if padding <= 0:
+        return pano
+    return torch.cat([pano[..., -padding:], pano, pano[..., :padding]], dim=-1)
+
+
+def unpad_pano(pano_pad, padding):
+    """src/utils/pano.py:98-101."""
+    return pano_pad if padding <= 0 else pano_pad[..., padding:-padding]
+
+
+# ------------------------------------------------------------------------------- camera maps (host, fp64)
+def _axis_angle(v):
+    v = np.asarray(v, np.float64).reshape(3)
+    th = float(np.linalg.norm(v))
+    if th < 1e-15:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
+
+
+def _rotations(theta, phi):
+    """Yaw about z then pitch about the rotated y axis (e2p.py:23-26, p2e.py:23-26)."""
+    R1 = _axis_angle(np.array([0.0, 0.0, 1.0]) * np.radians(theta))
+    R2 = _axis_angle((R1 @ np.array([0.0, 1.0, 0.0])) * np.radians(-phi))
+    return R1, R2
+
+
+def perspective_lonlat(fov, theta, phi, h, w):
+    """(lon, lat) in radians of every pixel of a gnomonic view (e2p.py:9-40)."""
+    hfov = float(h) / w * fov
+    w_len, h_len = np.tan(np.radians(fov / 2.0)), np.tan(np.radians(hfov / 2.0))
+    ys = np.tile(np.linspace(-w_len, w_len, w), [h, 1])
+    zs = -np.tile(np.linspace(-h_len, h_len, h), [w, 1]).T
+    xs = np.ones([h, w], np.float32)
+    d = np.sqrt(xs ** 2 + ys ** 2 + zs ** 2)
+    rays = (np.stack((xs, ys, zs), axis=2) / d[:, :, None]).reshape(h * w, 3).T
+    R1, R2 = _rotations(theta, phi)
+    rays = (R2 @ (R1 @ rays)).T
+    return np.arctan2(rays[:, 1], rays[:, 0]).reshape(h, w), -np.arcsin(rays[:, 2]).reshape(h, w)
+
+
+def perspective_sample_points(eh, ew, fov, theta, phi, h, w):
+    """Equirect pixel coordinates (x, y) hit by every perspective pixel (e2p.py:43-56)."""
+    lon, lat = perspective_lonlat(fov, theta, phi, h, w)
+    cx, cy = (ew - 1) / 2.0, (eh - 1) / 2.0
+    return np.degrees(lon) / 180 * cx + cx, np.degrees(lat) / 90 * cy + cy
+
+
+def equirect_sample_points(ph, pw, fov, theta, phi, h, w):
+    """Perspective pixel coordinates (x, y) hit by every equirect pixel, and their validity (p2e.py:9-53)."""
+    hfov = float(ph) / pw * fov
+    w_len, h_len = np.tan(np.radians(fov / 2.0)), np.tan(np.radians(hfov / 2.0))
+    lon, lat = np.meshgrid(np.linspace(-180, 180, w), np.linspace(90, -90, h))
+    rays = np.stack((np.cos(np.radians(lon)) * np.cos(np.radians(lat)), np.sin(np.radians(lon)) * np.cos(np.radians(lat)),
+                     np.sin(np.radians(lat))), axis=2)
+    R1, R2 = _rotations(theta, phi)
+    rays = (np.linalg.inv(R1) @ (np.linalg.inv(R2) @ rays.reshape(h * w, 3).T)).T.reshape(h, w, 3)
+    front = rays[:, :, 0] > 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rays = rays / rays[:, :, 0:1]
+    inside = (-w_len < rays[:, :, 1]) & (rays[:, :, 1] < w_len) & (-h_len < rays[:, :, 2]) & (rays[:, :, 2] < h_len)
+    x = np.where(inside, (rays[:, :, 1] + w_len) / 2 / w_len * pw, 0)
+    y = np.where(inside, (-rays[:, :, 2] + h_len) / 2 / h_len * ph, 0)
+    return x, y, inside & front
+
+
+def camera_lists(cameras):
+    """FoV/theta/phi of the rig as Python floats; accepts [m] or [1, m] tensors / arrays."""
+    if "_lists" in cameras:
+        return cameras["_lists"]
+    out = []
+    for k in ("FoV", "theta", "phi"):
+        v = cameras[k]
+        v = v.detach().cpu().reshape(-1).tolist() if torch.is_tensor(v) else np.asarray(v).reshape(-1).tolist()
+        out.append([float(x) for x in v])
+    m = min(len(v) for v in out)
+    return [v[:m] for v in out]
+
+
+# ------------------------------------------------------------------------------- bilinear footprints
+def _footprint(points_x, points_y, H, W, valid=None):
+    """Dense [P, H*W] matrix whose row p holds the bilinear weights of sample point p on an H x W grid with
+    zero padding (== kornia remap(align_corners=True) / grid_sample of one-hot images)."""
+    x = torch.as_tensor(points_x, dtype=torch.float32).reshape(-1)
+    y = torch.as_tensor(points_y, dtype=torch.float32).reshape(-1)
+    # grid_sample's normalise / unnormalise round trip in fp32
+    x = ((2.0 * x / (W - 1) - 1.0) + 1.0) / 2.0 * (W - 1)
+    y = ((2.0 * y / (H - 1) - 1.0) + 1.0) / 2.0 * (H - 1)
+    x0, y0 = torch.floor(x), torch.floor(y)
+    out = torch.zeros(x.numel(), H * W, dtype=torch.float32)
+    rows = torch.arange(x.numel())
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xi, yi = x0 + dx, y0 + dy
+            wgt = (1 - (x - xi).abs()) * (1 - (y - yi).abs())
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            if valid is not None:
+                ok = ok & torch.as_tensor(valid).reshape(-1)
+            idx = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long()
+            out.index_put_((rows[ok], idx[ok]), wgt[ok], accumulate=True)
+    return out
+
+
+def _gauss5(device):
+    x = torch.arange(5, dtype=torch.float64) - 2.0
+    g = torch.exp(-(x ** 2) / 2.0)
+    return (g / g.sum()).float().to(device)
+
+
+def _blur5(x, circular_w):
+    """5x5 sigma=1 Gaussian; replicate borders, or circular along W (pad_pano(2) around the blur, utils.py:26-29)."""
+    g = _gauss5(x.device)
+    if circular_w:
+        x = torch.cat([x[..., -2:], x, x[..., :2]], dim=-1)
+        x = F.pad(x, (0, 0, 2, 2), mode="replicate")
+    else:
+        x = F.pad(x, (2, 2, 2, 2), mode="replicate")
+    x = F.conv2d(x, g.view(1, 1, 1, 5))
+    return F.conv2d(x, g.view(1, 1, 5, 1))
+
+
+def _row_normalise(t):
+    mx = torch.amax(t, dim=(1, 2, 3), keepdim=True)
+    mx = torch.where(mx == 0, torch.ones_like(mx), mx)
+    return t / mx * 2 - 1
+
+
+def cross_view_bias(ph, pw, eh, ew, cameras, opposite, device="cpu", chunk=4):
+    """Additive attention biases of one WarpAttn resolution (get_merged_masks, src/utils/utils.py:12-41).
+
+    Returns fp32 ``bias_e2p`` [eh*ew, m*ph*pw] (equirect queries over the keys of all views, ordered
+    (m, h, w)) and ``bias_p2e`` [m*ph*pw, eh*ew], values in [-1, 1].  ``opposite`` selects the antipodal
+    variant (get_oppo_masks, utils.py:91-142: source columns shifted by W/2, cameras yawed 180 degrees)."""
+    fov, theta, phi = camera_lists(cameras)
+    m, ne, npx = len(fov), eh * ew, ph * pw
+    A = torch.empty(m, ne, npx, device=device)            # e2p: weight of equi pixel e at the sample point of (m, p)
+    B = torch.empty(m, npx, ne, device=device)            # p2e: weight of pers pixel p at the sample point of (m, e)
+    shift = torch.arange(ne).reshape(eh, ew).roll(-(ew // 2), dims=1).reshape(-1) if opposite else None
+    for i in range(m):
+        px, py = perspective_sample_points(eh, ew, fov[i], theta[i], phi[i], ph, pw)
+        fp = _footprint(px, py, eh, ew).t()                # [ne, npx] indexed by the pixel that is HIT
+        if opposite:
+            fp = fp[shift]                                 # source e lights the antipodal pixel opp(e)
+        A[i] = fp.to(device)
+        ex, ey, ok = equirect_sample_points(ph, pw, fov[i], theta[i] + (180 if opposite else 0), phi[i], eh, ew)
+        B[i] = _footprint(ex, ey, ph, pw, valid=ok).t().to(device)
+    # "fix missing pixels" symmetrisation (utils.py:79-87)
+    pers_masks = torch.clamp(A + B.transpose(1, 2), 0, 1)                    # [m, ne, npx]
+    equi_masks = torch.clamp(B + pers_masks.transpose(1, 2), 0, 1)           # [m, npx, ne]
+    del A, B
+    pm = torch.empty_like(pers_masks)
+    em = torch.empty_like(equi_masks)
+    for i in range(0, m, chunk):                                             # blur + per-source max-normalise
+        pm[i:i + chunk] = _row_normalise(_blur5(pers_masks[i:i + chunk].reshape(-1, 1, ph, pw), False)).reshape(-1, ne, npx)
+        em[i:i + chunk] = _row_normalise(_blur5(equi_masks[i:i + chunk].reshape(-1, 1, eh, ew), True)).reshape(-1, npx, ne)
+    bias_e2p = pm.permute(1, 0, 2).reshape(ne, m * npx).contiguous()
+    bias_p2e = em.reshape(m * npx, ne).contiguous()
+    return bias_e2p, bias_p2e
+
+
+def spherical_coords(ph, pw, eh, ew, cameras):
+    """(lon, lat) of every pixel: pers [m, ph, pw, 2], equi [eh, ew, 2], fp32 (get_coords, utils.py:145-164)."""
+    lon, lat = np.meshgrid(np.linspace(-np.pi, np.pi, ew), np.linspace(np.pi / 2, -np.pi / 2, eh))
+    equi = torch.tensor(np.stack([lon, lat], axis=-1), dtype=torch.float32)
+    fov, theta, phi = camera_lists(cameras)
+    pers = [torch.tensor(np.stack(perspective_lonlat(f, t, p, ph, pw), axis=-1), dtype=torch.float32)
+            for f, t, p in zip(fov, theta, phi)]
+    return torch.stack(pers), equi
+
+
+def nearest_e2p_index(eh, ew, ph, pw, cameras):
+    """Per view, the flat equirect index each perspective pixel copies under nearest-neighbour E2P and a
+    validity flag (init_noise, pipeline_animation_inference_dual.py:361-387).  Uses the same fp32
+    normalise -> grid_sample(nearest) arithmetic as kornia.remap so ties resolve identically."""
+    fov, theta, phi = camera_lists(cameras)
+    idx_img = torch.arange(eh * ew, dtype=torch.float32).reshape(1, 1, eh, ew)
+    one_img = torch.ones(1, 1, eh, ew)
+    idx, ok = [], []
+    for f, t, p in zip(fov, theta, phi):
+        x, y = perspective_sample_points(eh, ew, f, t, p, ph, pw)
+        gx = 2.0 * torch.as_tensor(x, dtype=torch.float32) / (ew - 1) - 1.0
+        gy = 2.0 * torch.as_tensor(y, dtype=torch.float32) / (eh - 1) - 1.0
+        grid = torch.stack([gx, gy], dim=-1)[None]
+        idx.append(F.grid_sample(idx_img, grid, mode="nearest", padding_mode="zeros", align_corners=True)[0, 0].long())
+        ok.append(F.grid_sample(one_img, grid, mode="nearest", padding_mode="zeros", align_corners=True)[0, 0] > 0.5)
+    return torch.stack(idx), torch.stack(ok)

@@ -22,6 +22,7 @@ const char* im360_last_error(void);
 /* softmax(Q K^T * scale + bias) V, head dim D in {32, 64}; head h of batch b lives at
  * base + b*bs + row*rs + h*D.  bias (optional) is ONE [Nq, Nk] matrix shared by all (b, h).
  * accumulate != 0: out += out_scale * result (second KV set of the IP cross attention).
+ * kv_group: K/V batch index = query batch index / kv_group (one context per video, F frames of queries).
  * Replaces: xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
  *   diffusers/models/attention_processor.py:1264, 1351, 641 (spatial self / cross attention),
  *   animatediff/models/attention.py:113-148 (text + IP cross attention),
@@ -30,7 +31,7 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                    int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
-                   float scale, float out_scale, int accumulate, int dtype, void* stream);
+                   int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream);
 
 /* Temporal self-attention over F <= 64 frames on token-major activations [B, F, P, heads*d]
  * (q, k, v are three views with common strides, e.g. slices of a fused QKV projection).

@@ -1,0 +1,126 @@
+"""TEST-ONLY stand-ins for ``imagine360_amd.kernels`` written with plain torch ops.
+
+The product has no CPU path.  These functions restate the *contract* of each HIP kernel (argument
+meaning, layouts, the wrap / x_off / pad addressing modes) so that ``-m "not gpu"`` tests can exercise
+the host logic of imagine360_amd (block walk, layouts, caching, RNG order) in fp32 on a machine without
+a GPU, by monkeypatching the ``kernels`` module attributes.  The real kernels are checked against the
+oracle in tests/test_kernels_gpu.py; nothing outside tests/ imports this file.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+
+def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1):
+    B, Nq, C = q.shape
+    d = C // heads
+    if kv_group > 1:
+        k, v = k.repeat_interleave(kv_group, 0), v.repeat_interleave(kv_group, 0)
+    qh = q.reshape(B, Nq, heads, d).transpose(1, 2).float()
+    kh = k.reshape(B, -1, heads, d).transpose(1, 2).float()
+    vh = v.reshape(B, -1, heads, d).transpose(1, 2).float()
+    s = qh @ kh.transpose(-1, -2) * (d ** -0.5 if scale is None else scale)
+    if bias is not None:
+        s = s + bias.float()
+    o = (s.softmax(-1) @ vh).transpose(1, 2).reshape(B, Nq, C) * out_scale
+    if accumulate:
+        out += o.to(out.dtype)
+        return out
+    return o.to(q.dtype)
+
+
+def temporal_attention(qkv, B, Fr, P, heads):
+    C = qkv.shape[1] // 3
+    t = qkv.reshape(B, Fr, P, 3 * C).permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    o = attention(t[..., :C], t[..., C:2 * C], t[..., 2 * C:], heads)
+    return o.reshape(B, P, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * P, C).contiguous()
+
+
+def _pad_w(x_nchw, pad):
+    return x_nchw if pad <= 0 else torch.cat([x_nchw[..., -pad:], x_nchw, x_nchw[..., :pad]], dim=-1)
+
+
+def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
+    N, H, W, C = x.shape
+    xp = _pad_w(x.permute(0, 3, 1, 2).float(), pad).reshape(N, groups, -1)
+    mean = xp.mean(-1)
+    var = xp.var(-1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    cpg = C // groups
+    scale = rstd.repeat_interleave(cpg, 1) * gamma.float()[None]
+    shift = beta.float()[None] - mean.repeat_interleave(cpg, 1) * scale
+    return scale, shift
+
+
+def group_norm_apply(x, scale, shift, silu, pad=0):
+    y = _pad_w(x.permute(0, 3, 1, 2).float(), pad).permute(0, 2, 3, 1) * scale[:, None, None, :] + shift[:, None, None, :]
+    return (F.silu(y) if silu else y).to(x.dtype).contiguous()
+
+
+def group_norm(x, gamma, beta, groups, eps, silu=False, pad=0):
+    scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
+    return group_norm_apply(x, scale, shift, silu, pad)
+
+
+def pack_conv_weight(w, cin_pad=None):
+    Cout, Cin, kh, kw = w.shape
+    cin_pad = cin_pad or ((Cin + 31) // 32) * 32
+    cout_pad = ((Cout + 127) // 128) * 128
+    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=w.dtype, device=w.device)
+    out[:Cout, :, :Cin] = w.detach().permute(0, 2, 3, 1).reshape(Cout, kh * kw, Cin)
+    return out
+
+
+def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None, temb=None,
+           imgs_per_temb=1, res=None):
+    N, Hin, Win, Cin = x.shape
+    taps = w_packed.shape[1]
+    k = 3 if taps == 9 else 1
+    w = w_packed[:cout].reshape(cout, k, k, Cin).permute(0, 3, 1, 2).float()
+    g = x.permute(0, 3, 1, 2).float()
+    if up:
+        g = F.interpolate(g, scale_factor=2.0, mode="nearest")
+    Wc = g.shape[-1]
+    if k == 1:
+        y = F.conv2d(g, w)
+    else:
+        g = _pad_w(g, 1) if wrap else F.pad(g, (1, 1, 0, 0))
+        y = F.conv2d(F.pad(g, (0, 0, 1, 1)), w, stride=stride)
+    if wout is None:
+        wout = Wc // stride
+    y = y[..., x_off:x_off + wout] if stride == 1 else y[..., :wout]
+    y = y.permute(0, 2, 3, 1)
+    if bias is not None:
+        y = y + bias.float()
+    if temb is not None:
+        y = y + temb.float().repeat_interleave(imgs_per_temb, 0)[:, None, None, :]
+    if res is not None:
+        y = y + res.float()
+    return y.to(x.dtype).contiguous()
+
+
+def circular_pad_w(x, pad):
+    return torch.cat([x[..., -pad:, :], x, x[..., :pad, :]], dim=-2).contiguous()
+
+
+def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv):
+    return (cx * sample.float() + cv * (uncond.float() + guidance * (cond.float() - uncond.float()))).to(sample.dtype)
+
+
+_NAMES = ["attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
+          "conv2d", "circular_pad_w", "cfg_ddim_update"]
+
+
+@contextlib.contextmanager
+def patched_kernels():
+    """Route ``imagine360_amd.kernels.<fn>`` to the torch stand-ins for the duration of a CPU test."""
+    from imagine360_amd import kernels
+    saved = {n: getattr(kernels, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(kernels, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(kernels, n, f)
