@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the dual-branch denoising hot path (BASELINE.json metric: denoising steps/sec).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one CFG-batched MultiViewBaseModel.forward (both UNets + 7 WarpAttn) + CFG combine + the two
+DDIM updates, on synthetic inputs already resident in HBM.  N > 1 = sample-parallel
+(one independent sample per GPU, weights replicated, BASELINE config 3): weak scaling, no per-step
+collective, one all-gather of the final panorama latents at the latent boundary inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from imagine360_amd import configs, flops, kernels, synthetic  # noqa: E402
+from imagine360_amd.scheduler import DDIMScheduler  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+WORKLOADS = {
+    "cfg2": dict(frames=16, pano_hw=(64, 128), pers_hw=(32, 32), pers_px=256,
+                 desc="BASELINE cfg2: 16-frame 512x1024 equirect (pano latent 4x16x64x128 + 20 views 4x16x32x32), "
+                      "CFG batch 2, full-width random-init UNets, DDIM step"),
+    "cfg1": dict(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), pers_px=128,
+                 desc="BASELINE cfg1 shapes: 8-frame 256x512 equirect, CFG batch 2"),
+    "cfg5": dict(frames=16, pano_hw=(128, 256), pers_hw=(64, 64), pers_px=512,
+                 desc="BASELINE cfg5 shapes: 16-frame 1024x2048 equirect, CFG batch 2"),
+}
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores on a bounded
+    sample, scaled to the benchmarked workload by the analytic FLOP ratio."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from im360_oracle import mv as OMV
+    from im360_oracle.cfg import sd21_unet_cfg
+    wd, fr, phw, qhw = args.cpu_width_div, 8, (32, 64), (16, 16)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        mv = configs.build_mv_model(wd, device="cpu", dtype=torch.float32, xformers=True)
+        sd = dict(mv.state_dict())
+        del mv
+        cfg = sd21_unet_cfg(wd)
+        cfg.xformers = True
+        inp = synthetic.mv_inputs(frames=fr, pano_hw=phw, pers_hw=qhw, seed=0, sam_frames=16)
+        cams = synthetic.icosahedron_cameras(90, 128)
+        t0 = time.time()
+        OMV.mv_forward(sd, cfg, inp["latents"], inp["pano_latent"], inp["timestep"], inp["prompt_embd"],
+                       inp["pano_prompt_embd"], cams, inp["fps_tensor_pano"], inp["fps_tensor_pers"],
+                       inp["reference_images_clip_feat_pano"], inp["reference_images_clip_feat_pers"],
+                       inp["relative_position_tensor"], inp["pitchs_tensor"], mask_cache={})
+        dt = time.time() - t0
+    boc = tuple(cfg.block_out_channels)
+    sample_tf = flops.step_flops(frames=fr, pano_hw=phw, pers_hw=qhw, block_out_channels=boc) / 1e12
+    w = WORKLOADS[args.workload]
+    full_tf = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"]) / 1e12
+    cpu_tflops = sample_tf / dt
+    return {"value": cpu_tflops / full_tf, "unit": "denoising steps/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one oracle mv_forward (fp32, width/{wd} channels {boc}, 8 frames, pano latent 32x64, 20 views 16x16, "
+                      f"{sample_tf:.2f} TF analytic) took {dt:.1f} s = {cpu_tflops:.3f} TFLOP/s on {cores} host threads; "
+                      f"scaled to the {full_tf:.1f} TF step of {args.workload} by the FLOP ratio (IP-adapter conditioning "
+                      f"included in the timed sample, excluded from the FLOP count)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-width-div", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    w = WORKLOADS[args.workload]
+    torch.set_grad_enabled(False)
+    kernels.lib()
+    mv = configs.build_mv_model(args.width_div, device=dev, dtype=dt, xformers=True)
+    inp = synthetic.mv_inputs(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=1 + rank,
+                              sam_frames=max(16, w["frames"]), dtype=dt, device=dev)
+    cams = synthetic.icosahedron_cameras(90, w["pers_px"], device=dev)
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    nsteps_total = 25
+    sch.set_timesteps(nsteps_total)
+    ts_host = sch._timesteps_host
+    ts_dev = [torch.tensor([t], dtype=torch.int64, device=dev) for t in ts_host]
+    # CFG halves see the same latent (pipeline_animation_inference_dual.py:750-751); channels 0..3 are the noisy latent
+    pano_in = inp["pano_latent"]
+    pers_in = inp["latents"]
+    pano_lat = pano_in[:1, :4].contiguous()
+    pers_lat = pers_in[:1, :, :4].contiguous()
+    guidance = 7.5
+
+    def step(i):
+        nonlocal pano_lat, pers_lat
+        t = i % nsteps_total
+        pano_in[:, :4] = pano_lat
+        pers_in[:, :, :4] = pers_lat
+        pred_pers, pred_pano = mv(
+            latents=pers_in, pano_latent=pano_in, timestep=ts_dev[t], prompt_embd=inp["prompt_embd"],
+            pano_prompt_embd=inp["pano_prompt_embd"], cameras=cams, use_fps_condition=True,
+            use_ip_plus_cross_attention=True, fps_tensor_pano=inp["fps_tensor_pano"],
+            fps_tensor_pers=inp["fps_tensor_pers"],
+            reference_images_clip_feat_pano=inp["reference_images_clip_feat_pano"],
+            reference_images_clip_feat_pers=inp["reference_images_clip_feat_pers"],
+            relative_position_tensor=inp["relative_position_tensor"], pitchs_tensor=inp["pitchs_tensor"])
+        pano_lat = sch.fused_cfg_step(pred_pano[0:1], pred_pano[1:2], guidance, ts_host[t], pano_lat)
+        pers_lat = sch.fused_cfg_step(pred_pers[0:1], pred_pers[1:2], guidance, ts_host[t], pers_lat)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    prof_kinds = ["conv", "attn", "temporal", "gn_stats", "gn_apply"]
+    kernels.prof_enable(prof_kinds)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if dist is not None:          # latent boundary: gather every rank's panorama latent (1 MB each)
+        gathered = [torch.empty_like(pano_lat) for _ in range(world)]
+        dist.all_gather(gathered, pano_lat)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels.prof_enable([])
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(pano_lat.float()).all().item())
+
+    if rank == 0:
+        prof = {k: kernels.prof_collect(k) for k in prof_kinds}
+        boc = tuple(mv.unet.config.block_out_channels)
+        total, parts = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"],
+                                        block_out_channels=boc, breakdown=True)
+        conv_flops = parts["pers conv"] + parts["pano conv"]
+        attn_flops = parts["pers self-attn"] + parts["pano self-attn"] + parts["WarpAttn attn"]
+        conv_ms, conv_n = prof["conv"]
+        attn_ms, attn_n = prof["attn"]
+        conv_tfs = conv_flops * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        attn_tfs = attn_flops * args.steps / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+        steps_per_s = world * args.steps / elapsed
+        out = {
+            "metric": "denoising steps/sec (dual-branch UNet, 16x512x1024 latent)",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": w["desc"], "parallelism": f"sample-parallel x{world}" if world > 1 else "single GPU",
+                       "width_div": args.width_div, "ddim_steps_schedule": nsteps_total, "guidance": guidance,
+                       "tflop_per_step": total / 1e12, "outputs_finite": finite},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (GroupNorm+SiLU'd 3x3/1x1 conv, implicit GEMM)",
+                         "achieved": conv_tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tfs / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": conv_n / max(args.steps, 1), "avg_launch_ms": conv_ms / max(conv_n, 1),
+                         "algorithmic_tflop_per_step": conv_flops / 1e12},
+            "kernels": {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items()},
+            "attention": {"achieved": attn_tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tfs / MFMA_PEAK_TFLOPS,
+                          "algorithmic_tflop_per_step": attn_flops / 1e12,
+                          "note": "self-attention + WarpAttn QK^T/PV flops over all attn_fwd launches (cross-attention launches "
+                                  "included in the time, their small flops not counted)"},
+            "whole_step_tflops": total / 1e12 * steps_per_s / world,
+            "whole_step_frac_of_mfma_peak": total / 1e12 * steps_per_s / world / MFMA_PEAK_TFLOPS,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+            out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
