@@ -24,7 +24,7 @@ struct ConvParams {
     const void* x; const void* w; const void* bias; const void* temb; const void* res; void* y;
     int N, Hin, Win, Cin, Hout, Wout, Cout;
     int ntaps;          // 9 (3x3) or 1 (1x1)
-    int stride, up, wrap, x_off;
+    int stride, up, wrap, x_off, y_off;
     int imgs_per_temb;
     long M;             // N * Hout * Wout
     int tiles_n;        // ceil(Cout / 128)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            int gy = py[i] * p.stride + dy - 1;
+            int gy = py[i] * p.stride + dy - 1 + p.y_off;
             int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
             bool ok = pvalid[i] && gy >= 0 && gy < Hc;
             if (p.wrap) {
@@ -229,7 +229,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
                               const void* res, void* y,
                               int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
                               int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
-                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off,
+                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
                               int64_t imgs_per_temb, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "conv_fwd: null pointer");
@@ -245,7 +245,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     p.x = x; p.w = w_packed; p.bias = bias; p.temb = temb; p.res = res; p.y = y;
     p.N = (int)N; p.Hin = (int)Hin; p.Win = (int)Win; p.Cin = (int)Cin;
     p.Hout = (int)Hout; p.Wout = (int)Wout; p.Cout = (int)Cout; p.ntaps = (int)ntaps;
-    p.stride = (int)stride; p.up = up ? 1 : 0; p.wrap = wrap ? 1 : 0; p.x_off = (int)x_off;
+    p.stride = (int)stride; p.up = up ? 1 : 0; p.wrap = wrap ? 1 : 0; p.x_off = (int)x_off; p.y_off = (int)y_off;
     p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
     p.M = N * Hout * Wout;
     p.tiles_n = (int)((Cout + BN - 1) / BN);

@@ -22,7 +22,7 @@ _SIGNATURES = {
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
     "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
-    "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 13 + [_INT, _PTR]),
+    "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR]),
@@ -173,7 +173,7 @@ def pack_conv_weight(w, cin_pad=None):
 
 
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None,
-           temb=None, imgs_per_temb=1, res=None):
+           temb=None, imgs_per_temb=1, res=None, y_off=0):
     """x [N, Hin, Win, Cin] -> y [N, Hout, Wout, Cout] (3x3 pad 1 or 1x1, see im360_conv_fwd)."""
     _dev(x, w_packed, bias, temb, res)
     N, Hin, Win, Cin = x.shape
@@ -189,7 +189,7 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
     if temb is not None:
         assert temb.is_contiguous() and temb.shape[1] == cout and temb.shape[0] * imgs_per_temb == N
     rc = lib().im360_conv_fwd(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
-                              N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off,
+                              N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
                               imgs_per_temb, _dt(x), _stream())
     _check(rc, "im360_conv_fwd")
     return y

@@ -38,7 +38,8 @@ class DerivedCache:
         hit = self._store.get(key)
         if hit is None or hit[0] != sig:
             with torch.no_grad():
-                hit = (sig, build())
+                # the entry keeps its sources alive, so their addresses cannot be recycled by another tensor
+                hit = (sig, build(), tuple(params))
             self._store[key] = hit
         return hit[1]
 
@@ -60,13 +61,13 @@ class InflatedConv3d(nn.Conv2d):
     def cin_padded(self):
         return ((self.in_channels + 31) // 32) * 32
 
-    def forward_cl(self, x, wrap=False, up=False, x_off=0, wout=None, temb=None, imgs_per_temb=1, res=None):
+    def forward_cl(self, x, wrap=False, up=False, x_off=0, wout=None, temb=None, imgs_per_temb=1, res=None, y_off=0):
         """x [N, H, W, Cin(+zero pad to a multiple of 32)] channels-last."""
         if x.shape[-1] != self.cin_padded:
             x = F.pad(x, (0, self.cin_padded - x.shape[-1]))
         return kernels.conv2d(x, self.packed_weight(), self.out_channels, bias=self.bias, stride=self.stride[0],
                               up=up, wrap=wrap, x_off=x_off, wout=wout, temb=temb, imgs_per_temb=imgs_per_temb,
-                              res=res)
+                              res=res, y_off=y_off)
 
     def forward(self, x):
         if x.dim() == 5:

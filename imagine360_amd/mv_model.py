@@ -144,6 +144,14 @@ class MultiViewBaseModel(nn.Module):
             hit = cams
         return hit
 
+    def set_frame_shard(self, shard):
+        """Frame-chunk sharding (imagine360_amd.dist.FrameShard): the model is fed this rank's frames and every
+        motion-module attention exchanges tokens with one all-to-all each way."""
+        from .unet3d import VersatileAttention
+        for mod in self.modules():
+            if isinstance(mod, VersatileAttention):
+                mod.frame_shard = shard
+
     def _ip_noise(self, like):
         if self.noise_on_host:
             return torch.randn(like.shape, dtype=torch.float32).to(device=like.device, dtype=like.dtype)

@@ -137,8 +137,12 @@ def _blur5(x, circular_w):
         x = F.pad(x, (0, 0, 2, 2), mode="replicate")
     else:
         x = F.pad(x, (2, 2, 2, 2), mode="replicate")
-    x = F.conv2d(x, g.view(1, 1, 1, 5))
-    return F.conv2d(x, g.view(1, 1, 5, 1))
+    # separable 5-tap filter as shifted weighted sums (plain elementwise kernels; a conv2d call here would go
+    # through MIOpen's im2col path once per (view, pixel) image)
+    w = x.shape[-1] - 4
+    x = sum(g[i] * x[..., i:i + w] for i in range(5))
+    h = x.shape[-2] - 4
+    return sum(g[i] * x[..., i:i + h, :] for i in range(5))
 
 
 def _row_normalise(t):

@@ -246,14 +246,25 @@ class VersatileAttention(QKVAttention):
         self.pos_encoder = PositionalEncoding(query_dim, max_len=temporal_position_encoding_max_len) \
             if temporal_position_encoding else None
         self.is_cross_attention = False
+        self.frame_shard = None          # imagine360_amd.dist.FrameShard when frames are split across GPUs
 
     def forward(self, tokens, batch, frames, pixels):
-        """tokens [batch*frames*pixels, C] token-major."""
+        """tokens [batch*frames*pixels, C] token-major; ``frames`` = frames held by this rank."""
         c = tokens.shape[-1]
+        sh = self.frame_shard
+        f0 = sh.f0 if sh is not None else 0
         if self.pos_encoder is not None:
-            pe = self.pos_encoder.pe[0, :frames].to(tokens.dtype)
+            pe = self.pos_encoder.pe[0, f0:f0 + frames].to(tokens.dtype)
             tokens = (tokens.reshape(batch, frames, pixels, c) + pe[None, :, None, :]).reshape(-1, c)
-        a = kernels.temporal_attention(self.qkv(tokens), batch, frames, pixels, self.heads)
+        qkv = self.qkv(tokens)
+        if sh is None:
+            a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads)
+        else:
+            # frame-sharded -> pixel-sharded (one all-to-all over xGMI), full-length attention, and back
+            q = sh.frames_to_pixels(qkv.reshape(batch, frames, pixels, 3 * c))
+            pp = q.shape[2]
+            a = kernels.temporal_attention(q.reshape(-1, 3 * c), batch, sh.total, pp, self.heads)
+            a = sh.pixels_to_frames(a.reshape(batch, sh.total, pp, c), pixels).reshape(-1, c)
         return self.out_proj(a)
 
 

@@ -64,8 +64,8 @@ int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, v
 
 /* 3x3 (ntaps = 9) or 1x1 (ntaps = 1) convolution, implicit GEMM on MFMA.  x [N, Hin, Win, Cin],
  * y [N, Hout, Wout, Cout], w_packed from im360_pack_conv_weight.  stride 1|2; up: input is
- * nearest-upsampled x2 on the fly; wrap: circular W addressing; x_off: column offset into a
- * pre-padded input.  Epilogue: + bias[Cout] + temb[n / imgs_per_temb][Cout] + res[N, Hout, Wout, Cout].
+ * nearest-upsampled x2 on the fly; wrap: circular W addressing; x_off / y_off: column / row offset of the
+ * taps (pre-padded input; the VAE downsampler's (0,1,0,1) padding is x_off = y_off = 1).  Epilogue: + bias[Cout] + temb[n / imgs_per_temb][Cout] + res[N, Hout, Wout, Cout].
  * Replaces: InflatedConv3d / nn.Conv2d at animatediff/models/resnet.py:19-27, 84, 128, 183, 205, 218,
  *   227-251; unet.py:134-137, 358; pad_pano/unpad_pano around them (MVGenModel.py:138-143, 276-281,
  *   305-314, 449-456, 474-478); F.interpolate nearest (resnet.py:104); the VAE convs. */
@@ -73,7 +73,7 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
                    const void* res, void* y,
                    int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
                    int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
-                   int64_t stride, int64_t up, int64_t wrap, int64_t x_off,
+                   int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
                    int64_t imgs_per_temb, int dtype, void* stream);
 
 /* PyTorch conv weight [Cout, Cin, kh, kw] -> [CoutPad (mult. of 128)][kh*kw][CinPad (mult. of 32)]. */

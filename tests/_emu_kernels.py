@@ -73,7 +73,7 @@ def pack_conv_weight(w, cin_pad=None):
 
 
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None, temb=None,
-           imgs_per_temb=1, res=None):
+           imgs_per_temb=1, res=None, y_off=0):
     N, Hin, Win, Cin = x.shape
     taps = w_packed.shape[1]
     k = 3 if taps == 9 else 1
@@ -85,8 +85,14 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
     if k == 1:
         y = F.conv2d(g, w)
     else:
-        g = _pad_w(g, 1) if wrap else F.pad(g, (1, 1, 0, 0))
-        y = F.conv2d(F.pad(g, (0, 0, 1, 1)), w, stride=stride)
+        if stride == 2 and x_off == 1 and y_off == 1:        # taps at 2o .. 2o+2: zero pad right/bottom only
+            g = F.pad(g, (0, 1, 0, 1))
+            x_off = 0
+        else:
+            assert y_off == 0
+            g = _pad_w(g, 1) if wrap else F.pad(g, (1, 1, 0, 0))
+            g = F.pad(g, (0, 0, 1, 1))
+        y = F.conv2d(g, w, stride=stride)
     if wout is None:
         wout = Wc // stride
     y = y[..., x_off:x_off + wout] if stride == 1 else y[..., :wout]

@@ -1,0 +1,197 @@
+"""Host logic of the product (imagine360_amd) on CPU: the HIP kernels are replaced by the torch stand-ins
+of tests/_emu_kernels.py (the product itself has no CPU path), everything else -- block walk, channels-last
+layouts, fused/hoisted conditioning, geometry caches, RNG order, scheduler, pipeline -- is the shipped code,
+checked against fixtures generated from the REAL reference.  fp32 -> relative L2 <= 5e-5."""
+import json
+import os
+import random
+
+import pytest
+import torch
+
+import _emu_kernels as E
+from helpers import GOLDEN, gold, op_inputs, rel
+from imagine360_amd import configs, pano_geometry as G, synthetic as S
+from imagine360_amd.layers import from_cl, to_cl
+from imagine360_amd.scheduler import DDIMScheduler
+
+torch.set_grad_enabled(False)
+TOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def mv():
+    m = configs.build_mv_model(5, device="cpu", dtype=torch.float32, xformers=False)
+    m.noise_on_host = True
+    return m
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys_full.json")))
+    with torch.device("meta"):
+        from imagine360_amd.mv_model import MultiViewBaseModel
+        from imagine360_amd.vae import AutoencoderKL
+        mvm = MultiViewBaseModel(configs.build_unet(1), configs.build_unet(1))
+        vae = AutoencoderKL(**configs.vae_config(1))
+    assert {k: list(v.shape) for k, v in mvm.state_dict().items()} == keys["mv"]
+    assert {k: list(v.shape) for k, v in vae.state_dict().items()} == keys["vae"]
+
+
+def test_zero_initialised_layers_like_reference():
+    un = configs.build_unet(5)
+    assert un.fps_embedding.linear_2.weight.abs().sum() == 0
+    assert un.down_blocks[0].motion_modules[0].temporal_transformer.proj_out.weight.abs().sum() == 0
+    from imagine360_amd.mv_model import WarpAttn
+    w = WarpAttn(64)
+    assert w.transformer.attn1.to_out.weight.abs().sum() == 0 and w.transformer.ff.net[2].weight.abs().sum() == 0
+
+
+def test_blocks_against_reference(mv):
+    g, I, un = gold("ops_w5.npz"), op_inputs(), mv.pano_unet
+    with E.patched_kernels():
+        x, f = to_cl(I["x"])
+        assert rel(from_cl(un.down_blocks[0].resnets[0].forward_cl(x, I["emb"], f, pano=True), f), g["resnet_pano"]) < TOL
+        x2 = torch.cat([I["x"], I["x"].flip(1), 0.5 * I["x"].roll(3, 1)], 1)
+        assert rel(un.up_blocks[3].resnets[0](x2, I["emb"]), g["resnet_shortcut"]) < TOL
+        T = un.down_blocks[0].attentions[0]
+        assert rel(from_cl(T.forward_cl(x, I["ctx"], f), f), g["spatial_cpu"]) < TOL
+        un.enable_xformers_memory_efficient_attention()
+        assert rel(T(I["x"], encoder_hidden_states=I["ctx"]).sample, g["spatial_xf"]) < TOL
+        un.disable_xformers_memory_efficient_attention()
+        assert rel(un.down_blocks[0].motion_modules[0](I["x"], I["emb"], I["ctx"]), g["motion"]) < TOL
+        assert rel(from_cl(un.down_blocks[0].downsamplers[0].forward_cl(x, pano=True), f), g["down_pano"]) < TOL
+        x3, _ = to_cl(I["x3"])
+        assert rel(from_cl(un.up_blocks[0].upsamplers[0].forward_cl(x3, pano=True), f), g["up_pano"]) < TOL
+        l9, _ = to_cl(I["lat9"])
+        assert rel(from_cl(un.conv_in_cl(l9, pano=True), f), g["conv_in_pano"]) < TOL
+        assert rel(un.ip_tokens_clean(I["feat"]), g["ip_tokens"]) < 1e-4
+        cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 64).items()}
+        for tag, seed in (("normal", 0), ("oppo", 1)):
+            random.seed(seed)                                   # the coin is drawn inside, like the reference
+            p, e = mv.cp_blocks_encoder[0](I["px"], I["ex"], cams)
+            assert rel(p, g["warp_pers_" + tag]) < TOL and rel(e, g["warp_equi_" + tag]) < TOL
+
+
+def test_cross_view_geometry_against_reference():
+    g = gold("masks.npz")
+    for ph, eh in ((4, 8), (8, 16)):
+        cams = {k: v[0] for k, v in S.icosahedron_cameras(90, ph * 8).items()}
+        m, ne, npx = 20, eh * 2 * eh, ph * ph
+        for tag in ("normal", "oppo"):
+            b_e2p, b_p2e = G.cross_view_bias(ph, ph, eh, 2 * eh, cams, tag == "oppo")
+            ref_e2p = g[f"pers_{tag}_{ph}"].reshape(m, ne, npx).permute(1, 0, 2).reshape(ne, m * npx)
+            ref_p2e = g[f"equi_{tag}_{ph}"].reshape(m * npx, ne)
+            assert (b_e2p - ref_e2p).abs().max() < 1e-3 and (b_p2e - ref_p2e).abs().max() < 1e-3     # fp16 fixture
+        pc, ec = G.spherical_coords(ph, ph, eh, 2 * eh, cams)
+        assert torch.equal(pc, g[f"pers_coords_{ph}"]) and torch.equal(ec, g[f"equi_coords_{ph}"])
+
+
+def test_pad_pano_api():
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    p = G.pad_pano(x, 2)
+    assert p.shape[-1] == 9 and torch.equal(p[..., :2], x[..., -2:]) and torch.equal(p[..., -2:], x[..., :2])
+    assert torch.equal(G.unpad_pano(p, 2), x) and G.pad_pano(x, 0) is x
+
+
+def test_scheduler_against_reference():
+    g = gold("ddim.npz")
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    assert torch.equal(sch.alphas_cumprod, g["alphas_cumprod"])
+    gen = torch.Generator().manual_seed(5)
+    x, v = torch.randn(1, 4, 2, 8, 16, generator=gen), torch.randn(1, 4, 2, 8, 16, generator=gen)
+    for n in (4, 25, 50):
+        sch.set_timesteps(n)
+        assert torch.equal(sch.timesteps, g[f"timesteps_{n}"].long())
+        for idx in (0, n - 1):
+            assert rel(sch.step(v, sch.timesteps[idx], x).prev_sample, g[f"step_{n}_{idx}"]) < 1e-5
+    with E.patched_kernels():           # fused CFG + update == guidance then step
+        u, c = torch.randn(1, 4, 2, 8, 16, generator=gen), torch.randn(1, 4, 2, 8, 16, generator=gen)
+        t = sch._timesteps_host[3]
+        assert rel(sch.fused_cfg_step(u, c, 7.5, t, x), sch.step(u + 7.5 * (c - u), t, x).prev_sample) < 1e-6
+
+
+def test_vae_against_reference():
+    g = gold("vae_w4.npz")
+    vae = configs.build_vae(4, device="cpu", dtype=torch.float32)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 96, generator=gen) * 2 - 1
+    z = torch.randn(2, 4, 8, 20, generator=gen)
+    with E.patched_kernels():
+        assert rel(vae.encode(x, 2).latent_dist.parameters, g["moments"]) < TOL      # int return_dict like the pipeline
+        assert rel(vae.decode(z).sample, g["decoded"]) < TOL
+        vae.enable_slicing()
+        assert rel(vae.decode(z).sample, g["decoded"]) < TOL
+
+
+@pytest.mark.parametrize("xf,name", [(False, "mv_forward_w5.npz"), (True, "mv_forward_w5_xf.npz")])
+def test_mv_forward_against_reference(mv, xf, name):
+    g = gold(name)
+    inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=0, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    (mv.unet.enable_xformers_memory_efficient_attention if xf else mv.unet.disable_xformers_memory_efficient_attention)()
+    (mv.pano_unet.enable_xformers_memory_efficient_attention if xf else mv.pano_unet.disable_xformers_memory_efficient_attention)()
+    with E.patched_kernels():
+        torch.manual_seed(7)
+        random.seed(7)
+        mv.taps = {}
+        pers, pano = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **inp)
+    assert rel(pano, g["pano"]) < TOL and rel(pers[:, [0, 7, 13, 19]], g["pers_views"]) < TOL
+    if not xf:
+        for n, (tp, te) in mv.taps.items():
+            assert rel(from_cl(te, 8)[:, ::4, ::3], g[f"tap_{n}_equi"]) < TOL
+    mv.taps = None
+    mv.unet.disable_xformers_memory_efficient_attention()
+    mv.pano_unet.disable_xformers_memory_efficient_attention()
+
+
+def test_pipeline_against_reference(mv):
+    from imagine360_amd.pipeline import AnimationPipeline
+    g = gold("pipeline_w5.npz")
+    vae = configs.build_vae(4, device="cpu", dtype=torch.float32)
+    pipe = AnimationPipeline(vae, None, None, mv.unet, mv.pano_unet, mv, DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS), None, "SAM")
+    pipe.rng, pipe._no_progress = "host", True
+    pipe.enable_vae_slicing()
+    vb = S.video_batch(frames=16, pano_hw=(256, 512), seed=0)
+    cond = S.conditioning(frames=16, seed=0)
+    trace = []
+    with E.patched_kernels():
+        torch.manual_seed(21)
+        random.seed(21)
+        vid = pipe("synthetic", num_inference_steps=2, guidance_scale_text=7.5, negative_prompt="", latents_dtype=torch.float32,
+                   video_batch=vb, use_outpaint=True, use_ip_plus_cross_attention=True, use_fps_condition=True,
+                   ip_plus_condition="video", prompt_embeds=(cond["text_pano"], cond["text_pers"]),
+                   sam_features=(cond["sam_pano"], cond["sam_pers"]), trace=trace).videos
+    for i, t in enumerate(trace):
+        assert rel(t, g[f"pano_latent_{i}"]) < 1e-4
+    assert rel(vid[:, :, ::3, ::4, ::4], g["video_sub"]) < 1e-3
+    st = torch.stack([vid.mean(dim=(0, 1, 3, 4)), vid.std(dim=(0, 1, 3, 4))])
+    assert rel(st, g["video_frame_stats"]) < 1e-4
+    assert vid.dtype == torch.float32 and vid.shape == (1, 3, 16, 256, 512)
+
+
+def test_no_cpu_fallback_in_product():
+    from imagine360_amd import kernels
+    x = torch.zeros(1, 16, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        kernels.attention(x, x, x, heads=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        kernels.group_norm(torch.zeros(1, 2, 2, 32), torch.ones(32), torch.zeros(32), 32, 1e-5)
+
+
+def test_dropin_aliases():
+    import sys
+    from imagine360_amd import dropin
+    if any(n in sys.modules and not getattr(sys.modules[n], "__im360_alias__", False) for n in ("diffusers", "animatediff", "src")):
+        pytest.skip("reference modules already imported in this interpreter")
+    try:
+        dropin.install()
+        from animatediff.models.unet import UNet3DConditionModel
+        from animatediff.pipelines.pipeline_animation_inference_dual import AnimationPipeline
+        from diffusers import AutoencoderKL, DDIMScheduler
+        from src.models.MVGenModel import MultiViewBaseModel
+        from src.utils.pano import pad_pano, unpad_pano
+        import imagine360_amd.unet3d as U3
+        assert UNet3DConditionModel is U3.UNet3DConditionModel and callable(pad_pano) and callable(unpad_pano)
+        assert AnimationPipeline.__call__ and AutoencoderKL and DDIMScheduler and MultiViewBaseModel
+    finally:
+        dropin.uninstall()
