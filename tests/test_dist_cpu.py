@@ -1,0 +1,114 @@
+"""Multi-process paths on CPU (gloo, world_size 2): sample-parallel latent gather and the frame-chunk
+sharding of the motion modules (all-to-all frame-sharded <-> pixel-sharded tokens)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+torch.set_grad_enabled(False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return dict(ret)
+
+
+def _gather_job(rank, world):
+    from imagine360_amd import dist as D
+    lat = torch.full((1, 4, 2, 3, 5), float(rank + 1))
+    g = D.gather_latents(lat)
+    assert D.shard_samples(range(5)) == list(range(5))[rank::world]
+    return [float(g[i].mean()) for i in range(world)] + [list(g.shape)]
+
+
+def test_sample_parallel_latent_gather():
+    out = _run(_gather_job)
+    for r in range(2):
+        assert out[r][:2] == [1.0, 2.0] and out[r][2] == [2, 1, 4, 2, 3, 5]
+
+
+def _exchange_job(rank, world):
+    from imagine360_amd.dist import FrameShard
+    b, f, p, c = 2, 6, 7, 8                      # 7 pixels: exercises the zero-padded last pixel shard
+    full = torch.arange(b * f * p * c, dtype=torch.float32).reshape(b, f, p, c)
+    sh = FrameShard(f)
+    loc = sh.take(full, 1).contiguous()
+    px = sh.frames_to_pixels(loc)                # [b, f, ceil(p/world), c]
+    pp = px.shape[2]
+    lo = rank * pp
+    want = torch.zeros(b, f, pp, c)
+    n = max(0, min(p, lo + pp) - lo)
+    want[:, :, :n] = full[:, :, lo:lo + n]
+    ok1 = torch.equal(px, want)
+    back = sh.pixels_to_frames(px, p)
+    ok2 = torch.equal(back, loc)
+    ok3 = torch.equal(sh.gather_frames(loc, 1), full)
+    return bool(ok1 and ok2 and ok3)
+
+
+def test_frame_pixel_all_to_all_round_trip():
+    out = _run(_exchange_job)
+    assert out[0] and out[1]
+
+
+def _motion_job(rank, world):
+    import _emu_kernels as E
+    from imagine360_amd.dist import FrameShard
+    from imagine360_amd.layers import to_cl
+    from imagine360_amd.unet3d import VanillaTemporalModule, VersatileAttention
+    from imagine360_amd.weights import fill_module_
+    mm = VanillaTemporalModule(in_channels=64, num_attention_heads=8, num_transformer_block=1,
+                               temporal_position_encoding=True, temporal_position_encoding_max_len=64)
+    fill_module_(mm)
+    g = torch.Generator().manual_seed(3)
+    x5 = torch.randn(2, 64, 8, 3, 5, generator=g)                 # b c f h w, 8 frames, 15 pixels
+    with E.patched_kernels():
+        full = mm(x5)
+        sh = FrameShard(8)
+        for mod in mm.modules():
+            if isinstance(mod, VersatileAttention):
+                mod.frame_shard = sh
+        xl, fl = to_cl(sh.take(x5, 2).contiguous())
+        from imagine360_amd.layers import from_cl
+        loc = from_cl(mm.forward_cl(xl, fl), fl)
+    want = sh.take(full, 2)
+    return float((loc - want).abs().max() / want.abs().max())
+
+
+def test_frame_sharded_motion_module_matches_unsharded():
+    out = _run(_motion_job)
+    assert out[0] < 1e-5 and out[1] < 1e-5

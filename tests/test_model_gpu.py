@@ -1,0 +1,144 @@
+"""Model-level parity on the MI355X: the shipped product path (HIP kernels through the C ABI, 16-bit storage)
+against the CPU oracle / reference fixtures, plus size-independent properties at BASELINE cfg2 sizes.
+
+Tolerances (relative L2 of the whole tensor, fp32 oracle as truth): one dual-branch forward through ~60
+layers <= 5e-2 in bf16 / 1.5e-2 in fp16; VAE <= 3e-2; two-step pipeline video <= 5e-2."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import gold, rel  # noqa: E402
+from im360_oracle import mv as OMV, vae as OV  # noqa: E402
+from im360_oracle.cfg import sd21_unet_cfg, sd21_vae_cfg  # noqa: E402
+from imagine360_amd import configs, kernels as K, synthetic as S  # noqa: E402
+from imagine360_amd.scheduler import DDIMScheduler  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def _q(v, dt):
+    return v.to(dt).float() if torch.is_floating_point(v) else v
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 5e-2), (torch.float16, 1.5e-2)])
+def test_mv_forward_vs_oracle(dt, tol):
+    dev = torch.device("cuda", 0)
+    mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True)
+    mv.noise_on_host = True
+    inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=0, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    dinp = {k: (v.to(dev, dt) if torch.is_floating_point(v) else v.to(dev)) for k, v in inp.items()}
+    torch.manual_seed(7)
+    random.seed(7)
+    mv.taps = {}
+    pers, pano = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **dinp)
+    cfg = sd21_unet_cfg(5)
+    cfg.xformers = True
+    sd = {k: v.float().cpu() for k, v in mv.state_dict().items()}
+    torch.manual_seed(7)
+    random.seed(7)
+    otaps = {}
+    o_pers, o_pano = OMV.mv_forward(sd, cfg, _q(inp["latents"], dt), _q(inp["pano_latent"], dt), inp["timestep"],
+                                    _q(inp["prompt_embd"], dt), _q(inp["pano_prompt_embd"], dt), cams, inp["fps_tensor_pano"],
+                                    inp["fps_tensor_pers"], _q(inp["reference_images_clip_feat_pano"], dt),
+                                    _q(inp["reference_images_clip_feat_pers"], dt), inp["relative_position_tensor"],
+                                    inp["pitchs_tensor"], taps=otaps, mask_cache={})
+    assert rel(pano, o_pano) < tol and rel(pers, o_pers) < tol
+    from imagine360_amd.layers import from_cl
+    for n, (tp, te) in mv.taps.items():          # intermediate activations after each WarpAttn
+        assert rel(from_cl(te, 8), otaps[n][1]) < tol, n
+    # the reference fixture itself (generated from the real reference, xformers semantics)
+    g = gold("mv_forward_w5_xf.npz")
+    assert rel(pano, g["pano"]) < tol
+
+
+def test_vae_vs_oracle():
+    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    vae = configs.build_vae(4, device=dev, dtype=dt)
+    sd = {k: v.float().cpu() for k, v in vae.state_dict().items()}
+    cfg = sd21_vae_cfg(4)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 96, generator=gen) * 2 - 1
+    z = torch.randn(2, 4, 8, 20, generator=gen)
+    assert rel(vae.encode(x.to(dev, dt)).latent_dist.parameters, OV.encode_moments(sd, cfg, _q(x, dt))) < 3e-2
+    assert rel(vae.decode(z.to(dev, dt)).sample, OV.decode(sd, cfg, _q(z, dt))) < 3e-2
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 1e-1), (torch.float16, 3e-2)])
+def test_pipeline_vs_reference_fixture(dt, tol):
+    """Two DDIM steps + VAE decode on the GPU with host RNG, against the latents / video the REAL reference produced
+    (fp32, CPU semantics incl. the logit-scale-1.0 cross-attention quirk) for the same seeds.  CFG 7.5 amplifies the
+    16-bit error of the two predictions, hence the looser bound than for a single forward."""
+    from imagine360_amd.pipeline import AnimationPipeline
+    dev = torch.device("cuda", 0)
+    mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=False)
+    vae = configs.build_vae(4, device=dev, dtype=dt)
+    pipe = AnimationPipeline(vae, None, None, mv.unet, mv.pano_unet, mv, DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS), None, "SAM").to(dev)
+    pipe.rng, pipe._no_progress = "host", True
+    vb = S.video_batch(frames=16, pano_hw=(256, 512), seed=0)
+    cond = S.conditioning(frames=16, seed=0)
+    g = gold("pipeline_w5.npz")
+    trace = []
+    torch.manual_seed(21)
+    random.seed(21)
+    vid = pipe("synthetic", num_inference_steps=2, guidance_scale_text=7.5, negative_prompt="", latents_dtype=dt, video_batch=vb,
+               use_outpaint=True, use_ip_plus_cross_attention=True, use_fps_condition=True, ip_plus_condition="video",
+               prompt_embeds=(cond["text_pano"], cond["text_pers"]), sam_features=(cond["sam_pano"], cond["sam_pers"]),
+               trace=trace).videos
+    assert vid.shape == (1, 3, 16, 256, 512) and vid.dtype == torch.float32 and torch.isfinite(vid).all()
+    for i, t in enumerate(trace):
+        assert rel(t, g[f"pano_latent_{i}"]) < 5e-2, i
+    assert rel(vid[:, :, ::3, ::4, ::4], g["video_sub"]) < 5e-2
+
+
+# ------------------------------------------------------------------ properties at BASELINE cfg2 sizes
+def test_full_size_conv_is_equivariant_to_longitude_rotation():
+    """Pano L0 resnet conv (32 images 64x128x320): circular addressing => rolling the input along W rolls the output,
+    bit for bit (same per-pixel accumulation order)."""
+    dt, dev = torch.bfloat16, "cuda"
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(32, 64, 128, 320, generator=g).to(dev, dt)
+    w = (torch.randn(320, 320, 3, 3, generator=g) * (9 * 320) ** -0.5).to(dev, dt)
+    wp = K.pack_conv_weight(w)
+    y = K.conv2d(x, wp, 320, wrap=True)
+    y2 = K.conv2d(torch.roll(x, 37, dims=2).contiguous(), wp, 320, wrap=True)
+    assert torch.equal(torch.roll(y, 37, dims=2), y2)
+    # linearity in the input (fp32 accumulate, one rounding): conv(2x) == 2 conv(x) exactly in bf16
+    assert torch.equal(K.conv2d((x * 2).contiguous(), wp, 320, wrap=True), y * 2)
+
+
+def test_full_size_attention_properties():
+    """Pano L0 self-attention (32 frames x 5 heads, 8192 tokens, d 64): invariant to a permutation of the keys,
+    independent across batch entries, rows of softmax sum to one (V = 1 -> O = 1)."""
+    dt, dev = torch.bfloat16, "cuda"
+    g = torch.Generator().manual_seed(2)
+    B, N, H, D = 4, 8192, 5, 64
+    q, k, v = (torch.randn(B, N, H * D, generator=g).to(dev, dt) for _ in range(3))
+    o = K.attention(q, k, v, H)
+    perm = torch.randperm(N, generator=g).to(dev)
+    o2 = K.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous(), H)
+    assert rel(o2, o) < 4e-3
+    o3 = K.attention(q[1:2].contiguous(), k[1:2].contiguous(), v[1:2].contiguous(), H)
+    assert torch.equal(o3[0], o[1])
+    ones = torch.ones_like(v)
+    assert (K.attention(q, k, ones, H).float() - 1).abs().max() < 1e-2
+
+
+def test_full_size_groupnorm_and_temporal_properties():
+    dt, dev = torch.bfloat16, "cuda"
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(32, 64, 128, 320, generator=g) * 1.7 + 0.3).to(dev, dt)
+    gamma, beta = torch.ones(320, device=dev, dtype=dt), torch.zeros(320, device=dev, dtype=dt)
+    y = K.group_norm(x, gamma, beta, 32, 1e-5).float().reshape(32, 64 * 128, 32, 10)
+    assert y.mean(dim=(1, 3)).abs().max() < 2e-2 and (y.var(dim=(1, 3), unbiased=False) - 1).abs().max() < 2e-2
+    # pad-aware statistics == statistics of the explicitly padded tensor
+    xp = K.circular_pad_w(x, 2)
+    s1, h1 = K.group_norm_stats(x, gamma, beta, 32, 1e-5, pad=2)
+    s2, h2 = K.group_norm_stats(xp, gamma, beta, 32, 1e-5, pad=0)
+    assert rel(s1, s2) < 1e-5 and (h1 - h2).abs().max() < 1e-4
+    # a single frame attends only to itself: temporal attention returns V
+    qkv = torch.randn(2 * 1 * 8192, 3 * 320, generator=g).to(dev, dt)
+    assert torch.equal(K.temporal_attention(qkv, 2, 1, 8192, 8), qkv[:, 640:])
