@@ -14,8 +14,12 @@
 //
 // GEMM view: D^T[cout, pixel] = W[cout, (tap, cin)] * X^T[(tap, cin), pixel]; 128 x 128 tile per
 // 256-thread workgroup, 4 waves as 2 x 2, each wave 2 x 2 v_mfma_f32_32x32x16 tiles (64 fp32
-// accumulators), K-step = BK channels of one tap, register prefetch of step s+1 under the MFMAs of
-// step s, padded LDS pitch (BK + 8) so ds_read_b128 fragments are bank-conflict free.
+// accumulators), K-step = BK channels of one tap.  Both operands go HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds, 16 B per lane, no VGPR staging): the taps' shifted / wrapped / upsampled pixel
+// addresses are per-lane SOURCE addresses, out-of-image taps read a 16-byte zero chunk, and the XOR
+// swizzle that keeps ds_read_b128 fragment reads conflict-free is applied on the source side (the DMA
+// destination is lane-linear).  Double-buffered LDS, one barrier per K-step: step s+1 streams in under
+// the 16 MFMAs of step s.
 #include "common.h"
 
 namespace im360 {
@@ -33,14 +37,21 @@ struct ConvParams {
 
 constexpr int BM = 128, BN = 128;
 
+// 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
+__device__ uint4 g_zero_chunk[1];
+
 template <typename T, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
-    constexpr int PITCH = BK + 8;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-    constexpr int LD = (128 * CPR) / 256;       // chunks per thread per operand (2 for BK=32, 4 for BK=64)
+    constexpr int ROWB = BK * 2;                // bytes per tile row
+    constexpr int RPB = 256 / ROWB;             // tile rows per 256-byte LDS bank row
+    constexpr int LD = (128 * CPR) / 256;       // LDS-DMA loads per thread per operand per K-step
     constexpr int KC = BK / 16;
-    __shared__ __attribute__((aligned(16))) T a_lds[BM * PITCH];   // activations [pixel][k]
-    __shared__ __attribute__((aligned(16))) T b_lds[BN * PITCH];   // weights     [cout][k]
+    constexpr int TILE = 128 * ROWB;            // bytes of one operand tile
+    // [buffer][A | B]: unpadded row-major tiles written by global_load_lds (lane-linear destination), the
+    // 16-byte chunk position XOR-swizzled with the row so MFMA fragment reads (16 rows, one K chunk) hit 16
+    // different slots of the 256-byte bank row
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];
 
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
     long bid = blockIdx.x;
@@ -59,15 +70,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int Hc = p.up ? 2 * p.Hin : p.Hin, Wc = p.up ? 2 * p.Win : p.Win;
     const T* xg = (const T*)p.x;
     const T* wg = (const T*)p.w;
+    const T* zero = (const T*)g_zero_chunk;
 
-    // per-thread pixel coordinates of the activation chunks this thread stages
-    int pn[LD], py[LD], pxx[LD], pc8[LD], prow[LD];
+    // per-thread staging slots: chunk c = i * 256 + tid -> tile row c / CPR, LDS position c % CPR
+    int pn[LD], py[LD], pxx[LD], pd8[LD], prow[LD];
     bool pvalid[LD];
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
         const int c = tid + i * 256;
         prow[i] = c / CPR;
-        pc8[i] = c % CPR;
+        pd8[i] = ((c % CPR) ^ ((prow[i] / RPB) & (CPR - 1))) * 8;      // data chunk (elements) stored at this position
         const long m = m0 + prow[i];
         pvalid[i] = m < p.M;
         const long mm = pvalid[i] ? m : 0;
@@ -87,15 +99,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
     const int ksteps_per_tap = p.Cin / BK;
     const int nsteps = p.ntaps * ksteps_per_tap;
-    uint4 areg[LD], breg[LD];
 
-    auto load_step = [&](int s) {
+    auto stage = [&](int s, int buf) {
         const int tap = s / ksteps_per_tap;
         const int c0 = (s % ksteps_per_tap) * BK;
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
+        char* abase = lds + buf * 2 * TILE + wid * 1024;
+        char* bbase = abase + TILE;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
             int gy = py[i] * p.stride + dy - 1 + p.y_off;
             int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
             bool ok = pvalid[i] && gy >= 0 && gy < Hc;
@@ -105,35 +117,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             } else {
                 ok = ok && gx >= 0 && gx < Wc;
             }
-            if (ok) {
-                const int sy = gy >> p.up, sx = gx >> p.up;
-                v = *(const uint4*)(xg + (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0 + pc8[i] * 8);
-            }
-            areg[i] = v;
-            breg[i] = *(const uint4*)(wg + ((long)(n0 + prow[i]) * p.ntaps + tap) * p.Cin + c0 + pc8[i] * 8);
-        }
-    };
-    auto store_step = [&]() {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            *(uint4*)(a_lds + prow[i] * PITCH + pc8[i] * 8) = areg[i];
-            *(uint4*)(b_lds + prow[i] * PITCH + pc8[i] * 8) = breg[i];
+            const int sy = gy >> p.up, sx = gx >> p.up;
+            const T* asrc = ok ? xg + (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0 + pd8[i] : zero;
+            const T* bsrc = wg + ((long)(n0 + prow[i]) * p.ntaps + tap) * p.Cin + c0 + pd8[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
+                                             (__attribute__((address_space(3))) void*)(abase + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc,
+                                             (__attribute__((address_space(3))) void*)(bbase + i * 4096), 16, 0, 0);
         }
     };
 
-    load_step(0);
+    // fragment byte offsets inside a tile: row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16)
+    int woff[2][KC], xoff[2][KC];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int rw = wn * 64 + a * 32 + col, rx = wm * 64 + a * 32 + col;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int d = kc * 2 + hi;
+            woff[a][kc] = rw * ROWB + ((d ^ ((rw / RPB) & (CPR - 1))) * 16);
+            xoff[a][kc] = rx * ROWB + ((d ^ ((rx / RPB) & (CPR - 1))) * 16);
+        }
+    }
+
+    stage(0, 0);
     for (int s = 0; s < nsteps; ++s) {
-        __syncthreads();
-        store_step();
-        __syncthreads();
-        if (s + 1 < nsteps) load_step(s + 1);
+        __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
+        if (s + 1 < nsteps) stage(s + 1, (s + 1) & 1);
+        const char* at = lds + (s & 1) * 2 * TILE;
+        const char* bt = at + TILE;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             uint4 wf[2], xf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                wf[a] = *(const uint4*)(b_lds + (wn * 64 + a * 32 + col) * PITCH + kc * 16 + hi * 8);
-                xf[a] = *(const uint4*)(a_lds + (wm * 64 + a * 32 + col) * PITCH + kc * 16 + hi * 8);
+                wf[a] = *(const uint4*)(bt + woff[a][kc]);
+                xf[a] = *(const uint4*)(at + xoff[a][kc]);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)

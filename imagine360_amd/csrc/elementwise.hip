@@ -1,0 +1,161 @@
+// HBM-bound token-wise kernels for gfx950: LayerNorm (with the two positional-encoding adds of the
+// reference fused in) and the GEGLU gate.
+//
+// Replaces:
+//   nn.LayerNorm call sites of the transformer blocks (animatediff/models/attention.py:463-507,
+//   motion_module.py:249,256; src/modules/transformer.py:160-165) together with
+//     pre-add : `query + query_pe`, `context + pe` before norm1 in WarpAttn (transformer.py:156-163,
+//               src/modules/attn_perspano.py:56,63)
+//     post-add: the temporal PositionalEncoding added to the normalised tokens (motion_module.py:349-350)
+//   GEGLU: hidden * gelu(gate) (diffusers/models/activations.py:93-125; src/modules/transformer.py:10-16)
+#include "common.h"
+
+namespace im360 {
+
+// one wave per token row; row values stay in registers between the two statistics passes
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                         const T* __restrict__ beta, const T* __restrict__ pre,
+                                                         const T* __restrict__ post, T* __restrict__ y, long rows, int C,
+                                                         long pre_period, long post_div, long post_mod, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    const T* xr = x + row * C;
+    const T* pr = pre ? pre + (row % pre_period) * C : nullptr;
+    float v[MAXCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nch) {
+            unpack8<T>(*(const uint4*)(xr + ch * 8), v[k]);
+            if (pr) {
+                float a[8];
+                unpack8<T>(*(const uint4*)(pr + ch * 8), a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[k][e] += a[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[k][e];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[k][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+    const T* po = post ? post + ((row / post_div) % post_mod) * C : nullptr;
+    T* yr = y + row * C;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int ch = lane + k * 64;
+        if (ch < nch) {
+            float g[8], b[8], o[8];
+            unpack8<T>(*(const uint4*)(gamma + ch * 8), g);
+            unpack8<T>(*(const uint4*)(beta + ch * 8), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+            if (po) {
+                float a[8];
+                unpack8<T>(*(const uint4*)(po + ch * 8), a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += a[e];
+            }
+            *(uint4*)(yr + ch * 8) = pack8<T>(o);
+        }
+    }
+}
+
+// h [rows, 2*I] = (a | gate) -> out [rows, I] = a * gelu(gate), exact (erf) GELU
+template <typename T>
+__global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8) {
+    const long total = rows * I8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / I8;
+        const int c = (int)(i % I8);
+        const uint4* hr = (const uint4*)h + r * 2 * I8;
+        float a[8], g[8];
+        unpack8<T>(hr[c], a);
+        unpack8<T>(hr[I8 + c], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f));
+        ((uint4*)out)[i] = pack8<T>(a);
+    }
+}
+
+template <typename T>
+static int launch_ln(const void* x, const void* gamma, const void* beta, const void* pre, const void* post, void* y,
+                     long rows, int C, long pre_period, long post_div, long post_mod, float eps, hipStream_t s) {
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    const int nch = C / 8;
+#define IM360_LN(MC)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<T, MC>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)gamma,    \
+                       (const T*)beta, (const T*)pre, (const T*)post, (T*)y, rows, C, pre_period, post_div,       \
+                       post_mod, eps)
+    if (nch <= 64) IM360_LN(1);
+    else if (nch <= 128) IM360_LN(2);
+    else if (nch <= 192) IM360_LN(3);
+    else IM360_LN(4);
+#undef IM360_LN
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+}  // namespace im360
+
+// y[r] = LN(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod]; pre/post optional
+extern "C" int im360_layernorm(const void* x, const void* gamma, const void* beta, const void* pre, const void* post,
+                               void* y, int64_t rows, int64_t C, int64_t pre_period, int64_t post_div,
+                               int64_t post_mod, float eps, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
+    IM360_CHECK_ARG(rows > 0 && C > 0 && (C % 8) == 0 && C <= 2048, "layernorm: C=%ld must be a multiple of 8, <= 2048", (long)C);
+    IM360_CHECK_ARG(!pre || pre_period > 0, "layernorm: pre_period must be positive");
+    IM360_CHECK_ARG(!post || (post_div > 0 && post_mod > 0), "layernorm: post_div/post_mod must be positive");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                    ((uintptr_t)beta % 16) == 0, "layernorm: misaligned pointer");
+    IM360_CHECK_ARG((rows + 3) / 4 <= 0x7fffffffL, "layernorm: too many rows");
+    ProfScope prof(PROF_MISC, stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0) return launch_ln<__bf16>(x, gamma, beta, pre, post, y, rows, (int)C, pre_period, post_div, post_mod, eps, s);
+    if (dtype == 1) return launch_ln<_Float16>(x, gamma, beta, pre, post, y, rows, (int)C, pre_period, post_div, post_mod, eps, s);
+    im360_set_error("layernorm: dtype %d unsupported", dtype);
+    return IM360_ERR_UNSUPPORTED;
+}
+
+// h [rows, 2*I] -> out [rows, I] = h[:, :I] * gelu(h[:, I:])
+extern "C" int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(h && out, "geglu: null pointer");
+    IM360_CHECK_ARG(rows > 0 && I > 0 && (I % 8) == 0, "geglu: I=%ld must be a multiple of 8", (long)I);
+    IM360_CHECK_ARG(((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0, "geglu: misaligned pointer");
+    const long total = rows * (I / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    ProfScope prof(PROF_MISC, stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0)
+        hipLaunchKernelGGL((geglu_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)h, (__bf16*)out, (long)rows, (int)(I / 8));
+    else if (dtype == 1)
+        hipLaunchKernelGGL((geglu_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)h, (_Float16*)out, (long)rows, (int)(I / 8));
+    else {
+        im360_set_error("geglu: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}

@@ -5,8 +5,8 @@
 // including the '(b f) d c -> (b d) f c' / back layout shuffles (motion_module.py:348, 427): the
 // kernel indexes the token-major activations [B, F, P, heads*d] with strides instead of moving them.
 //
-// HBM-bound (16x16 scores, AI ~ 8 flop/B): no MFMA.  One thread owns one (batch, pixel, frame i,
-// head) query row; the F threads of a pixel read the same K/V rows, so those loads are L1
+// HBM-bound (16x16 scores, AI ~ 8 flop/B): no MFMA.  One thread owns QPT query rows of one (batch, pixel,
+// head); the threads of a pixel read the same K/V rows, so those loads are L1
 // broadcasts and HBM sees q, k, v, o exactly once.  Adjacent lanes are adjacent heads of the same
 // token, so a wave's 16-byte loads cover whole contiguous token rows.
 #include "common.h"
@@ -24,76 +24,110 @@ struct TAttnParams {
     float scale_log2;
 };
 
-template <typename T, int FMAX>
+// QPT query frames per thread: each K/V chunk fetched from L1 is reused for QPT queries, which cuts the
+// L1 request count (the limiter of the one-query-per-thread form) by QPT
+template <typename T, int FMAX, int QPT>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnParams p) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= p.total) return;
+    const int ngrp = (p.F + QPT - 1) / QPT;
     const int h = (int)(gid % p.heads);
     long r = gid / p.heads;
-    const int i = (int)(r % p.F);
-    r /= p.F;
+    const int ig = (int)(r % ngrp);
+    r /= ngrp;
     const int px = (int)(r % p.P);
     const int b = (int)(r / p.P);
     const int d = p.d, nch = d >> 3;
-    const T* qp = (const T*)p.q + (long)b * p.q_bs + (long)px * p.q_ps + (long)i * p.q_fs + (long)h * d;
+    const T* qp = (const T*)p.q + (long)b * p.q_bs + (long)px * p.q_ps + (long)h * d;
     const T* kp = (const T*)p.k + (long)b * p.k_bs + (long)px * p.k_ps + (long)h * d;
     const T* vp = (const T*)p.v + (long)b * p.v_bs + (long)px * p.v_ps + (long)h * d;
-    T* op = (T*)p.out + (long)b * p.o_bs + (long)px * p.o_ps + (long)i * p.o_fs + (long)h * d;
-
-    float s[FMAX];
+    T* op = (T*)p.out + (long)b * p.o_bs + (long)px * p.o_ps + (long)h * d;
+    int qi[QPT];
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
+    for (int t = 0; t < QPT; ++t) qi[t] = min(ig * QPT + t, p.F - 1);      // clamped duplicates are not stored
+
+    float s[QPT][FMAX];
+#pragma unroll
+    for (int t = 0; t < QPT; ++t)
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) s[t][j] = 0.f;
     for (int c = 0; c < nch; ++c) {
-        float qf[8];
-        unpack8<T>(*(const uint4*)(qp + c * 8), qf);
+        float qf[QPT][8];
+#pragma unroll
+        for (int t = 0; t < QPT; ++t) unpack8<T>(*(const uint4*)(qp + (long)qi[t] * p.q_fs + c * 8), qf[t]);
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
             if (j < p.F) {
                 float kf[8];
                 unpack8<T>(*(const uint4*)(kp + (long)j * p.k_fs + c * 8), kf);
-                float acc = s[j];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(qf[e], kf[e], acc);
-                s[j] = acc;
+                for (int t = 0; t < QPT; ++t) {
+                    float acc = s[t][j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = fmaf(qf[t][e], kf[e], acc);
+                    s[t][j] = acc;
+                }
             }
         }
     }
-    float m = -INFINITY;
+    float inv[QPT];
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-        s[j] = (j < p.F) ? s[j] * p.scale_log2 : -INFINITY;
-        m = fmaxf(m, s[j]);
-    }
-    float l = 0.f;
+    for (int t = 0; t < QPT; ++t) {
+        float m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-        s[j] = __builtin_amdgcn_exp2f(s[j] - m);
-        l += s[j];
+        for (int j = 0; j < FMAX; ++j) {
+            s[t][j] = (j < p.F) ? s[t][j] * p.scale_log2 : -INFINITY;
+            m = fmaxf(m, s[t][j]);
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+            s[t][j] = __builtin_amdgcn_exp2f(s[t][j] - m);
+            l += s[t][j];
+        }
+        inv[t] = 1.0f / l;
     }
-    const float inv = 1.0f / l;
     for (int c = 0; c < nch; ++c) {
-        float of[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float of[QPT][8];
+#pragma unroll
+        for (int t = 0; t < QPT; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[t][e] = 0.f;
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
             if (j < p.F) {
                 float vf[8];
                 unpack8<T>(*(const uint4*)(vp + (long)j * p.v_fs + c * 8), vf);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) of[e] = fmaf(s[j], vf[e], of[e]);
+                for (int t = 0; t < QPT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) of[t][e] = fmaf(s[t][j], vf[e], of[t][e]);
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) of[e] *= inv;
-        *(uint4*)(op + c * 8) = pack8<T>(of);
+        for (int t = 0; t < QPT; ++t) {
+            if (ig * QPT + t < p.F) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) of[t][e] *= inv[t];
+                *(uint4*)(op + (long)qi[t] * p.o_fs + c * 8) = pack8<T>(of[t]);
+            }
+        }
     }
+}
+
+template <typename T, int FMAX, int QPT>
+static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
+    const long ngrp = (p.F + QPT - 1) / QPT;
+    p.total = (long)(p.total / p.F) * ngrp;          // B * P * heads * query groups
+    const long blocks = (p.total + 255) / 256;
+    hipLaunchKernelGGL((temporal_attn_kernel<T, FMAX, QPT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
 }
 
 template <typename T>
 static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
-    const long blocks = (p.total + 255) / 256;
-    if (p.F <= 16) hipLaunchKernelGGL((temporal_attn_kernel<T, 16>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
-    else if (p.F <= 32) hipLaunchKernelGGL((temporal_attn_kernel<T, 32>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((temporal_attn_kernel<T, 64>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    if (p.F <= 16) launch_tattn_v<T, 16, 4>(p, stream);
+    else if (p.F <= 32) launch_tattn_v<T, 32, 2>(p, stream);
+    else launch_tattn_v<T, 64, 1>(p, stream);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -26,11 +26,13 @@ _SIGNATURES = {
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR]),
+    "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
+    "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
     "im360_prof_enable": (None, [ctypes.c_uint]),
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
-PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4}
+PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5}
 
 
 def exported_symbols():
@@ -193,6 +195,35 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
                               imgs_per_temb, _dt(x), _stream())
     _check(rc, "im360_conv_fwd")
     return y
+
+
+# ------------------------------------------------------------------------------------------ token-wise
+def layer_norm(x, gamma, beta, eps=1e-5, pre=None, post=None, post_div=1):
+    """LayerNorm over the last dim of x [..., C] (rows flattened).  ``pre`` [P, C]: added to row r as
+    pre[r % P] before normalising; ``post`` [Q, C]: post[(r // post_div) % Q] added to the result."""
+    _dev(x, gamma, beta, pre, post)
+    C = x.shape[-1]
+    assert x.is_contiguous() and gamma.dtype == x.dtype
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    for t in (pre, post):
+        assert t is None or (t.is_contiguous() and t.shape[-1] == C and t.dtype == x.dtype)
+    rc = lib().im360_layernorm(_p(x), _p(gamma), _p(beta), _p(pre), _p(post), _p(y), rows, C,
+                               pre.shape[0] if pre is not None else 1, post_div,
+                               post.shape[0] if post is not None else 1, float(eps), _dt(x), _stream())
+    _check(rc, "im360_layernorm")
+    return y
+
+
+def geglu(h):
+    """h [..., 2*I] -> h[..., :I] * gelu(h[..., I:])."""
+    _dev(h)
+    assert h.is_contiguous()
+    I = h.shape[-1] // 2
+    out = torch.empty(h.shape[:-1] + (I,), dtype=h.dtype, device=h.device)
+    rc = lib().im360_geglu(_p(h), _p(out), h.numel() // (2 * I), I, _dt(h), _stream())
+    _check(rc, "im360_geglu")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ misc

@@ -93,6 +93,11 @@ class InflatedGroupNorm(nn.GroupNorm):
         return self.forward_cl(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
 
 
+def layer_norm(norm, x, pre=None, post=None, post_div=1):
+    """nn.LayerNorm parameters, HIP kernel (optionally fused with the positional-encoding adds)."""
+    return kernels.layer_norm(x.contiguous(), norm.weight, norm.bias, norm.eps, pre=pre, post=post, post_div=post_div)
+
+
 class GEGLU(nn.Module):
     """x -> a * gelu(gate), (a | gate) = proj(x)  (diffusers/models/activations.py:93-125)."""
 
@@ -101,9 +106,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h = self.proj(x)
-        a, gate = h.chunk(2, dim=-1)
-        return a * F.gelu(gate)
+        return kernels.geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):

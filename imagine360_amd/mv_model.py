@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import kernels
 from . import pano_geometry as G
-from .layers import DerivedCache, FeedForward, QKVAttention, to_cl
+from .layers import DerivedCache, FeedForward, QKVAttention, layer_norm, to_cl
 
 
 class SphericalPE(nn.Module):
@@ -91,16 +91,16 @@ class WarpAttn(nn.Module):
         eq = equi.reshape(b * frames, eh * ew, c)
         # (b m) f (h w) c -> (b f) (m h w) c
         pr = pers.reshape(b, m, frames, ph * pw, c).permute(0, 2, 1, 3, 4).reshape(b * frames, m * ph * pw, c)
-        eq_n = t.norm1(eq + equi_pe)
-        pr_n = t.norm1(pr + pers_pe)
+        eq_n = layer_norm(t.norm1, eq, pre=equi_pe)             # LN(x + pe), the PE add fused into the norm
+        pr_n = layer_norm(t.norm1, pr, pre=pers_pe)
         qkv_e, qkv_p = t.attn1.qkv(eq_n), t.attn1.qkv(pr_n)
         h = t.attn1.heads
         a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p)
         a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e)
         eq = t.attn1.to_out(a_e) + eq
-        eq = t.ff(t.norm2(eq)) + eq
+        eq = t.ff(layer_norm(t.norm2, eq)) + eq
         pr = t.attn1.to_out(a_p) + pr
-        pr = t.ff(t.norm2(pr)) + pr
+        pr = t.ff(layer_norm(t.norm2, pr)) + pr
         pers_out = pr.reshape(b, frames, m, ph, pw, c).permute(0, 2, 1, 3, 4, 5).reshape(nf, ph, pw, c)
         return pers_out.contiguous(), eq.reshape(ne_img, eh, ew, c)
 

@@ -16,7 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels
-from .layers import (DerivedCache, FeedForward, InflatedConv3d, InflatedGroupNorm, QKVAttention, from_cl, to_cl)
+from .layers import (DerivedCache, FeedForward, InflatedConv3d, InflatedGroupNorm, QKVAttention, from_cl, layer_norm,
+                     to_cl)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -181,9 +182,9 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states=None, frames=None, **_):
         y = hidden_states
-        y = self.attn1.out_proj(self.attn1.self_attention(self.norm1(y))) + y
-        y = self.attn2(self.norm2(y), encoder_hidden_states, frames=frames) + y
-        return self.ff(self.norm3(y)) + y
+        y = self.attn1.out_proj(self.attn1.self_attention(layer_norm(self.norm1, y))) + y
+        y = self.attn2(layer_norm(self.norm2, y), encoder_hidden_states, frames=frames) + y
+        return self.ff(layer_norm(self.norm3, y)) + y
 
 
 @dataclass
@@ -248,14 +249,21 @@ class VersatileAttention(QKVAttention):
         self.is_cross_attention = False
         self.frame_shard = None          # imagine360_amd.dist.FrameShard when frames are split across GPUs
 
+    def frame_pe(self, frames, dtype):
+        """PE rows of this rank's frames [frames, C] in the activation dtype (cached), or None."""
+        if self.pos_encoder is None:
+            return None
+        f0 = self.frame_shard.f0 if self.frame_shard is not None else 0
+        key = (f0, frames, dtype, self.pos_encoder.pe.device)
+        if getattr(self, "_pe_key", None) != key:
+            self._pe_key, self._pe_val = key, self.pos_encoder.pe[0, f0:f0 + frames].to(dtype).contiguous()
+        return self._pe_val
+
     def forward(self, tokens, batch, frames, pixels):
-        """tokens [batch*frames*pixels, C] token-major; ``frames`` = frames held by this rank."""
+        """tokens [batch*frames*pixels, C] token-major, ALREADY normalised and with the frame PE added (the
+        block's fused LayerNorm does both); ``frames`` = frames held by this rank."""
         c = tokens.shape[-1]
         sh = self.frame_shard
-        f0 = sh.f0 if sh is not None else 0
-        if self.pos_encoder is not None:
-            pe = self.pos_encoder.pe[0, f0:f0 + frames].to(tokens.dtype)
-            tokens = (tokens.reshape(batch, frames, pixels, c) + pe[None, :, None, :]).reshape(-1, c)
         qkv = self.qkv(tokens)
         if sh is None:
             a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads)
@@ -279,8 +287,9 @@ class TemporalTransformerBlock(nn.Module):
 
     def forward(self, y, batch, frames, pixels):
         for attn, norm in zip(self.attention_blocks, self.norms):
-            y = attn(norm(y), batch, frames, pixels) + y
-        return self.ff(self.ff_norm(y)) + y
+            n = layer_norm(norm, y, post=attn.frame_pe(frames, y.dtype), post_div=pixels)      # LN, then + PE[frame]
+            y = attn(n, batch, frames, pixels) + y
+        return self.ff(layer_norm(self.ff_norm, y)) + y
 
 
 class TemporalTransformer3DModel(nn.Module):

@@ -91,6 +91,19 @@ int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_
 int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
                           float guidance, float cx, float cv, int dtype, void* stream);
 
+/* y[r] = LayerNorm(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod] on token rows
+ * [rows, C]; pre / post are optional [*, C] tables (the WarpAttn spherical PE added before norm1, the motion
+ * module's frame PE added after the norm).
+ * Replaces: nn.LayerNorm at animatediff/models/attention.py:463-507, motion_module.py:249-256 (+ PE add :349-350),
+ *   src/modules/transformer.py:156-165 (+ `query + query_pe`, attn_perspano.py:56,63). */
+int im360_layernorm(const void* x, const void* gamma, const void* beta, const void* pre, const void* post,
+                    void* y, int64_t rows, int64_t C, int64_t pre_period, int64_t post_div,
+                    int64_t post_mod, float eps, int dtype, void* stream);
+
+/* out[rows, I] = h[:, :I] * gelu(h[:, I:]) (exact erf GELU).
+ * Replaces: GEGLU, diffusers/models/activations.py:93-125; src/modules/transformer.py:10-16. */
+int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream);
+
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
  * 3 gn_stats, 4 gn_apply).  collect() synchronises on the recorded events. */
 void im360_prof_enable(unsigned mask);

@@ -114,7 +114,24 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv):
     return (cx * sample.float() + cv * (uncond.float() + guidance * (cond.float() - uncond.float()))).to(sample.dtype)
 
 
-_NAMES = ["attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
+def layer_norm(x, gamma, beta, eps=1e-5, pre=None, post=None, post_div=1):
+    C = x.shape[-1]
+    t = x.reshape(-1, C).float()
+    r = torch.arange(t.shape[0])
+    if pre is not None:
+        t = t + pre.float()[r % pre.shape[0]]
+    y = F.layer_norm(t, (C,), gamma.float(), beta.float(), eps)
+    if post is not None:
+        y = y + post.float()[(r // post_div) % post.shape[0]]
+    return y.to(x.dtype).reshape(x.shape)
+
+
+def geglu(h):
+    a, g = h.float().chunk(2, dim=-1)
+    return (a * F.gelu(g)).to(h.dtype)
+
+
+_NAMES = ["layer_norm", "geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
           "conv2d", "circular_pad_w", "cfg_ddim_update"]
 
 

@@ -199,3 +199,25 @@ def test_bad_arguments_fail_loudly():
         K.attention(x.cpu(), x.cpu(), x.cpu(), heads=1)
     with pytest.raises(TypeError):
         K.group_norm(torch.zeros(1, 2, 2, 32, device="cuda"), torch.ones(32, device="cuda"), torch.zeros(32, device="cuda"), 32, 1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 64), (513, 1280), (40, 1024), (9, 2048)])
+def test_layer_norm_plain_pre_post(dt, rows, C):
+    x = q16(rnd(rows, C, seed=40) * 1.3 + 0.2, dt)
+    g, b = q16(1 + 0.1 * rnd(C, seed=41), dt), q16(0.1 * rnd(C, seed=42), dt)
+    dx, dg, db = x.to(dt).cuda(), g.to(dt).cuda(), b.to(dt).cuda()
+    assert rel(K.layer_norm(dx, dg, db, 1e-5), F.layer_norm(x, (C,), g, b, 1e-5)) < TOL[dt]
+    pre = q16(rnd(7, C, seed=43), dt)                    # WarpAttn form: LN(x + pe[row % P])
+    r = torch.arange(rows)
+    assert rel(K.layer_norm(dx, dg, db, 1e-5, pre=pre.to(dt).cuda()), F.layer_norm(x + pre[r % 7], (C,), g, b, 1e-5)) < TOL[dt]
+    post = q16(rnd(5, C, seed=44), dt)                   # motion-module form: LN(x) + pe[(row // P) % F]
+    ref = F.layer_norm(x, (C,), g, b, 1e-5) + post[(r // 3) % 5]
+    assert rel(K.layer_norm(dx, dg, db, 1e-5, post=post.to(dt).cuda(), post_div=3), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_geglu(dt):
+    h = q16(rnd(333, 2 * 1280, seed=45) * 2, dt)
+    a, g = h.chunk(2, dim=-1)
+    assert rel(K.geglu(h.to(dt).cuda()), a * F.gelu(g)) < TOL[dt]
