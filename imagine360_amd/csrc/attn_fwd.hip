@@ -32,9 +32,10 @@ struct AttnParams {
 
 constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between rescales
 
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+template <typename T, int D, int NW, bool HAS_BIAS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
     constexpr int VP = KVB + 4;        // V^T tile pitch (elements)
@@ -85,23 +86,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
             const int c = tid + i * NT;
-            const int row = c / (D / 8), c8 = c % (D / 8);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c < KCH && kv0 + row < p.Nk) v = *(const uint4*)(kb_ + (long)(kv0 + row) * p.k_rs + c8 * 8);
-            kreg[i] = v;
+            const int row = (c / (D / 8)) % KVB, c8 = c % (D / 8);
+            // unconditional loads (rows clamped into range): a predicated load inside an unrolled loop makes hipcc
+            // branch around it and drain vmcnt per load.  Out-of-range keys are masked to -inf below, so their
+            // (finite, duplicated) K/V rows never contribute.
+            const int rr = min(kv0 + row, p.Nk - 1);
+            kreg[i] = *(const uint4*)(kb_ + (long)rr * p.k_rs + (c8 % (D / 8)) * 8);
         }
 #pragma unroll
         for (int i = 0; i < VLD; ++i) {
             const int c = tid + i * NT;
             const int kp = c / (D / 8), c8 = c % (D / 8);
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (c < VIT) {
-                const int r0 = kv0 + 2 * kp;
-                if (r0 < p.Nk) v0 = *(const uint4*)(vb + (long)r0 * p.v_rs + c8 * 8);
-                if (r0 + 1 < p.Nk) v1 = *(const uint4*)(vb + (long)(r0 + 1) * p.v_rs + c8 * 8);
-            }
-            vreg[i][0] = v0;
-            vreg[i][1] = v1;
+            const int r0 = min(kv0 + 2 * (kp % (KVB / 2)), p.Nk - 1), r1 = min(kv0 + 2 * (kp % (KVB / 2)) + 1, p.Nk - 1);
+            vreg[i][0] = *(const uint4*)(vb + (long)r0 * p.v_rs + c8 * 8);
+            vreg[i][1] = *(const uint4*)(vb + (long)r1 * p.v_rs + c8 * 8);
         }
     };
     auto store_tile = [&]() {
@@ -151,38 +149,49 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
                 s[kb] = Elem<T>::mfma32(a, qf[dc], s[kb]);
             }
         }
-        // ---- logits in log2 domain, bias, key-range mask, tile max
-        float mloc = -INFINITY;
+        // ---- scores u (raw s, or s*scale + bias in the log2 domain when a bias is present), tile max
+        const float sc = HAS_BIAS ? 1.0f : p.scale_log2;            // p = exp2(u * sc - m * sc)
+        if (HAS_BIAS) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int key0 = kv0 + kb * 32 + 8 * g + 4 * hi;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias != nullptr && key0 < p.Nk) {
+                for (int g = 0; g < 4; ++g) {
+                    const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, p.Nk - 4);     // Nk % 4 == 0 (checked on the host)
                     const uint2 w = *(const uint2*)(bias + (long)qrow * p.bias_rs + key0);
-                    bv[0] = unpack_lo<T>(w.x) * LOG2E; bv[1] = unpack_hi<T>(w.x) * LOG2E;
-                    bv[2] = unpack_lo<T>(w.y) * LOG2E; bv[3] = unpack_hi<T>(w.y) * LOG2E;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float tv = s[kb][4 * g + j] * p.scale_log2 + bv[j];
-                    if (key0 + j >= p.Nk) tv = -INFINITY;
-                    s[kb][4 * g + j] = tv;
-                    mloc = fmaxf(mloc, tv);
+                    s[kb][4 * g + 0] = fmaf(s[kb][4 * g + 0], p.scale_log2, unpack_lo<T>(w.x) * LOG2E);
+                    s[kb][4 * g + 1] = fmaf(s[kb][4 * g + 1], p.scale_log2, unpack_hi<T>(w.x) * LOG2E);
+                    s[kb][4 * g + 2] = fmaf(s[kb][4 * g + 2], p.scale_log2, unpack_lo<T>(w.y) * LOG2E);
+                    s[kb][4 * g + 3] = fmaf(s[kb][4 * g + 3], p.scale_log2, unpack_hi<T>(w.y) * LOG2E);
                 }
             }
         }
+        if (kv0 + KVB > p.Nk) {                                     // only the last, partial tile masks keys
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + kb * 32 + mfma32_row(r, hi) >= p.Nk) s[kb][r] = -INFINITY;
+        }
+        float mloc = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
+        // deferred rescale: keep the old running max while the tile max exceeds it by less than RESCALE_THR
+        // (log2 units), so P <= 2^THR and the O / l rescale pass is skipped for most tiles
+        if (__any(mloc * sc > m_run * sc + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < DV; ++i)
+            for (int i = 0; i < DV; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        // ---- P = exp2(t - m), packed straight into MFMA B-operand order
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        // ---- P = exp2(u * sc - m * sc), packed straight into MFMA B-operand order
+        const float msc = m_run * sc;
         uint4 pf[2][2];
         float lsum = 0.f;
 #pragma unroll
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -msc));
                 lsum += pv[r];
             }
             pf[kb][0] = pack8<T>(pv);
@@ -240,21 +249,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-template <typename T, int D>
-static int launch_attn(const AttnParams& p, hipStream_t stream) {
+template <typename T, int D, bool HAS_BIAS>
+static int launch_attn_b(const AttnParams& p, hipStream_t stream) {
     dim3 grid(p.B * p.H, 1, 1);
     if (p.Nq <= 32) {
         grid.y = (p.Nq + 31) / 32;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1>), grid, dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
     } else if (p.Nq <= 64) {
         grid.y = (p.Nq + 63) / 64;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2>), grid, dim3(128), 0, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, HAS_BIAS>), grid, dim3(128), 0, stream, p);
     } else {
         grid.y = (p.Nq + 127) / 128;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
+}
+
+template <typename T, int D>
+static int launch_attn(const AttnParams& p, hipStream_t stream) {
+    return p.bias ? launch_attn_b<T, D, true>(p, stream) : launch_attn_b<T, D, false>(p, stream);
 }
 
 }  // namespace im360
@@ -277,7 +291,7 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     IM360_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                     ((uintptr_t)out % 8) == 0, "attn_fwd: misaligned base pointer");
     if (bias) {
-        IM360_CHECK_ARG((Nk % 4) == 0 && (bias_rs % 4) == 0 && ((uintptr_t)bias % 8) == 0,
+        IM360_CHECK_ARG((Nk % 4) == 0 && Nk >= 4 && (bias_rs % 4) == 0 && ((uintptr_t)bias % 8) == 0,
                         "attn_fwd: bias needs Nk %% 4 == 0 and 8-byte aligned rows");
     }
     AttnParams p;

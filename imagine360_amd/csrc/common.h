@@ -32,9 +32,10 @@ template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T
 
 // pack two fp32 into one dword of two T (lo = first element in memory)
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    T a = (T)lo, b = (T)hi;
-    uint16_t ua = __builtin_bit_cast(uint16_t, a), ub = __builtin_bit_cast(uint16_t, b);
-    return (uint32_t)ua | ((uint32_t)ub << 16);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef T tx2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tx2));     // one v_cvt_pk_{bf16,f16}_f32
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t w) {
     uint16_t u = (uint16_t)(w & 0xffffu);

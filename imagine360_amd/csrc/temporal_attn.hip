@@ -57,16 +57,16 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnParams p) {
         for (int t = 0; t < QPT; ++t) unpack8<T>(*(const uint4*)(qp + (long)qi[t] * p.q_fs + c * 8), qf[t]);
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
-            if (j < p.F) {
-                float kf[8];
-                unpack8<T>(*(const uint4*)(kp + (long)j * p.k_fs + c * 8), kf);
+            // unconditional load of a clamped frame: a predicated load here makes hipcc branch around every load
+            // and drain vmcnt per element (dependent L2 round trips); frames >= F are masked to -inf below
+            float kf[8];
+            unpack8<T>(*(const uint4*)(kp + (long)min(j, p.F - 1) * p.k_fs + c * 8), kf);
 #pragma unroll
-                for (int t = 0; t < QPT; ++t) {
-                    float acc = s[t][j];
+            for (int t = 0; t < QPT; ++t) {
+                float acc = s[t][j];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc = fmaf(qf[t][e], kf[e], acc);
-                    s[t][j] = acc;
-                }
+                for (int e = 0; e < 8; ++e) acc = fmaf(qf[t][e], kf[e], acc);
+                s[t][j] = acc;
             }
         }
     }
@@ -95,14 +95,12 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnParams p) {
             for (int e = 0; e < 8; ++e) of[t][e] = 0.f;
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
-            if (j < p.F) {
-                float vf[8];
-                unpack8<T>(*(const uint4*)(vp + (long)j * p.v_fs + c * 8), vf);
+            float vf[8];                                    // frames >= F carry probability exactly 0
+            unpack8<T>(*(const uint4*)(vp + (long)min(j, p.F - 1) * p.v_fs + c * 8), vf);
 #pragma unroll
-                for (int t = 0; t < QPT; ++t)
+            for (int t = 0; t < QPT; ++t)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) of[t][e] = fmaf(s[t][j], vf[e], of[t][e]);
-            }
+                for (int e = 0; e < 8; ++e) of[t][e] = fmaf(s[t][j], vf[e], of[t][e]);
         }
 #pragma unroll
         for (int t = 0; t < QPT; ++t) {

@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmarks at BASELINE cfg2 shapes (run on the MI355X):
+
+    python tools/bench_kernels.py [attn] [conv] [temporal] [ln] [gn] [--iters N]
+
+Prints achieved TFLOP/s (MFMA kernels, vs 2500 dense bf16) or GB/s (HBM kernels, vs 8000) per shape.
+Usable under `rocprofv3 --pmc ...` for counters of one kernel class.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagine360_amd import kernels as K  # noqa: E402
+
+DT = torch.bfloat16
+DEV = "cuda"
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def rn(*s):
+    return torch.randn(*s, device=DEV, dtype=torch.float32).to(DT)
+
+
+def bench_attn(iters):
+    shapes = [("pano L0 self", 32, 5, 8192, 8192, 64, False), ("pers L0 self", 640, 5, 1024, 1024, 64, False),
+              ("pano L1 self", 32, 10, 2048, 2048, 64, False), ("pers L1 self", 640, 10, 256, 256, 64, False),
+              ("pano L2 self", 32, 20, 512, 512, 64, False), ("pers L0 cross text", 640, 5, 1024, 77, 64, False),
+              ("warp L1 e2p", 32, 10, 2048, 5120, 32, True), ("warp L1 p2e", 32, 10, 5120, 2048, 32, True),
+              ("warp L2 e2p", 32, 20, 512, 1280, 32, True)]
+    for name, B, H, Nq, Nk, D, bias in shapes:
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        bb = (torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT) if bias else None
+        t = timeit(lambda: K.attention(q, k, v, H, bias=bb), iters)
+        fl = 4.0 * B * H * Nq * Nk * D
+        print(f"attn  {name:20s} B={B:4d} H={H:2d} Nq={Nq:5d} Nk={Nk:5d} d={D}: {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TF/s "
+              f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
+
+
+def bench_conv(iters):
+    shapes = [("pers L0 320->320", 640, 32, 32, 320, 320, False), ("pano L0 320->320 (W+4)", 32, 64, 132, 320, 320, False),
+              ("pers L1 640->640", 640, 16, 16, 640, 640, False), ("pers L2 1280->1280", 640, 8, 8, 1280, 1280, False),
+              ("pers L3 1280->1280", 640, 4, 4, 1280, 1280, False), ("pers up L0 960->320", 640, 32, 32, 960, 320, False),
+              ("pers up L1 1920->640", 640, 16, 16, 1920, 640, False), ("pano L0 wrap s1", 32, 64, 128, 320, 320, True)]
+    for name, N, H, W, Ci, Co, wrap in shapes:
+        x = rn(N, H, W, Ci)
+        w = K.pack_conv_weight(rn(Co, Ci, 3, 3) * (9 * Ci) ** -0.5)
+        b = rn(Co)
+        t = timeit(lambda: K.conv2d(x, w, Co, bias=b, wrap=wrap), iters)
+        fl = 2.0 * N * H * W * Ci * Co * 9
+        print(f"conv  {name:26s} N={N:3d} {H:3d}x{W:3d} {Ci:4d}->{Co:4d}: {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TF/s "
+              f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
+
+
+def bench_temporal(iters):
+    for name, B, Fr, P, C in [("pers L0", 40, 16, 1024, 320), ("pano L0", 2, 16, 8192, 320), ("pers L1", 40, 16, 256, 640),
+                              ("pers L2", 40, 16, 64, 1280)]:
+        qkv = rn(B * Fr * P, 3 * C)
+        t = timeit(lambda: K.temporal_attention(qkv, B, Fr, P, 8), iters)
+        by = 4.0 * B * Fr * P * C * 2
+        print(f"tattn {name:10s} B={B:3d} F={Fr} P={P:5d} C={C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak)")
+
+
+def bench_ln(iters):
+    for name, rows, C in [("pers L0", 655360, 320), ("pano L0", 262144, 320), ("pers L1", 163840, 640), ("pers L2", 40960, 1280)]:
+        x, g, b = rn(rows, C), rn(C), rn(C)
+        t = timeit(lambda: K.layer_norm(x, g, b), iters)
+        by = 2.0 * rows * C * 2
+        print(f"ln    {name:10s} rows={rows:7d} C={C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak)")
+        h = rn(rows, 8 * C) if rows * C * 16 < 8e9 else None
+        if h is not None:
+            t = timeit(lambda: K.geglu(h), iters)
+            by = 3.0 * rows * 4 * C * 2
+            print(f"geglu {name:10s} rows={rows:7d} I={4 * C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak)")
+
+
+def bench_gn(iters):
+    for name, N, H, W, C, pad in [("pers L0", 640, 32, 32, 320, 0), ("pano L0 pad2", 32, 64, 128, 320, 2), ("pers L1", 640, 16, 16, 640, 0),
+                                  ("pers up L0 960", 640, 32, 32, 960, 0)]:
+        x, g, b = rn(N, H, W, C), rn(C), rn(C)
+        t1 = timeit(lambda: K.group_norm_stats(x, g, b, 32, 1e-5, pad), iters)
+        s, h = K.group_norm_stats(x, g, b, 32, 1e-5, pad)
+        t2 = timeit(lambda: K.group_norm_apply(x, s, h, True, pad), iters)
+        by = N * H * W * C * 2.0
+        print(f"gn    {name:14s} N={N:3d} {H}x{W} C={C:4d}: stats {t1 * 1e3:7.3f} ms {by / t1 / 1e9:6.0f} GB/s | apply {t2 * 1e3:7.3f} ms "
+              f"{2 * by / t2 / 1e9:6.0f} GB/s")
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    iters = 10
+    if "--iters" in sys.argv:
+        iters = int(sys.argv[sys.argv.index("--iters") + 1])
+        args = [a for a in args if a != str(iters)]
+    which = args or ["attn", "conv", "temporal", "ln", "gn"]
+    torch.set_grad_enabled(False)
+    for w in which:
+        globals()["bench_" + w](iters)
