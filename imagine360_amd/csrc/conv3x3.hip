@@ -100,30 +100,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int ksteps_per_tap = p.Cin / BK;
     const int nsteps = p.ntaps * ksteps_per_tap;
 
-    auto stage = [&](int s, int buf) {
-        const int tap = s / ksteps_per_tap;
-        const int c0 = (s % ksteps_per_tap) * BK;
+    // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
+    // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
+    // steps; the packed weights [cout][tap][cin] are contiguous across taps, so their pointers just keep advancing.
+    const T* aptr[LD];
+    const T* bptr[LD];
+    int ainc[LD];
+#pragma unroll
+    for (int i = 0; i < LD; ++i) bptr[i] = wg + (long)(n0 + prow[i]) * p.ntaps * p.Cin + pd8[i];
+    int tap_p = 0, kk_p = 0;
+    auto set_tap = [&](int tap) {
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
-        char* abase = lds + buf * 2 * TILE + wid * 1024;
-        char* bbase = abase + TILE;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {
             int gy = py[i] * p.stride + dy - 1 + p.y_off;
             int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
             bool ok = pvalid[i] && gy >= 0 && gy < Hc;
             if (p.wrap) {
-                gx = gx % Wc;
-                if (gx < 0) gx += Wc;
+                gx = gx < 0 ? gx + Wc : (gx >= Wc ? gx - Wc : gx);      // |shift| <= 2 < Wc: one conditional wrap
             } else {
                 ok = ok && gx >= 0 && gx < Wc;
             }
             const int sy = gy >> p.up, sx = gx >> p.up;
-            const T* asrc = ok ? xg + (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + c0 + pd8[i] : zero;
-            const T* bsrc = wg + ((long)(n0 + prow[i]) * p.ntaps + tap) * p.Cin + c0 + pd8[i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)asrc,
+            const long off = ok ? (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + pd8[i] : 0;
+            aptr[i] = ok ? xg + off : zero;
+            ainc[i] = ok ? BK : 0;
+        }
+    };
+    set_tap(0);
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
+
+    auto stage = [&](int buf) {
+        char* abase = lds + buf * 2 * TILE + wid_s * 1024;
+        char* bbase = abase + TILE;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
                                              (__attribute__((address_space(3))) void*)(abase + i * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bsrc,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[i],
                                              (__attribute__((address_space(3))) void*)(bbase + i * 4096), 16, 0, 0);
+            aptr[i] += ainc[i];
+            bptr[i] += BK;
+        }
+        if (++kk_p == ksteps_per_tap) {
+            kk_p = 0;
+            if (++tap_p < p.ntaps) set_tap(tap_p);
         }
     };
 
@@ -140,10 +161,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     }
 
-    stage(0, 0);
+    stage(0);
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
-        if (s + 1 < nsteps) stage(s + 1, (s + 1) & 1);
+        if (s + 1 < nsteps) stage((s + 1) & 1);
         const char* at = lds + (s & 1) * 2 * TILE;
         const char* bt = at + TILE;
 #pragma unroll
