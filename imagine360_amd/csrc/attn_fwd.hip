@@ -23,6 +23,7 @@ namespace im360 {
 struct AttnParams {
     const void* q; const void* k; const void* v; const void* bias; void* out;
     int B, H, Nq, Nk;
+    int nqt;             // query tiles per (batch, head)
     int kv_group;        // K/V batch index = query batch index / kv_group (context shared by the frames of a video)
     long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, bias_rs;   // element strides
     float scale_log2;    // logit scale * log2(e)
@@ -38,7 +39,7 @@ template <typename T, int D, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
-    constexpr int VP = KVB + 4;        // V^T tile pitch (elements)
+    constexpr int VP = KVB;            // V^T tile pitch (elements): unpadded, 16-byte groups XOR-swizzled by row
     constexpr int DC = D / 16;         // k-steps of the QK^T contraction
     constexpr int DV = D / 32;         // 32-wide blocks of the output head dim
     constexpr int KCH = KVB * D / 8;   // 16-byte chunks in a K tile
@@ -46,15 +47,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int VIT = (KVB / 2) * (D / 8);   // (key pair, 8-channel chunk) items of a V tile
     constexpr int VLD = (VIT + NT - 1) / NT;
 
-    __shared__ __attribute__((aligned(16))) T k_lds[KVB * KP];
-    __shared__ __attribute__((aligned(16))) T vt_lds[D * VP];
+    // double-buffered K / V^T tiles: one barrier per KV tile (the next tile is written while this one is consumed)
+    __shared__ __attribute__((aligned(16))) T k_lds2[2][KVB * KP];
+    __shared__ __attribute__((aligned(16))) T vt_lds2[2][D * VP];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x;
+    // XCD-aware block order: the dispatcher deals consecutive block ids round-robin to the 8 XCDs (private L2s).
+    // Give every XCD one contiguous range of the (batch*head major, q-tile minor) space, so the ~100 workgroups
+    // resident on an XCD at any moment share ONE head's K/V (2 MB at 8192 keys) in that XCD's 4 MB L2 instead of
+    // each streaming its own from HBM.
+    long lb = blockIdx.x;
+    {
+        const long nb = gridDim.x, qn = nb / 8, rn = nb % 8, xcd = lb % 8, idx = lb / 8;
+        lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    }
+    const int bh = (int)(lb / p.nqt);
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = blockIdx.y * (32 * NW) + wid * 32;
+    const int q0 = (int)(lb % p.nqt) * (32 * NW) + wid * 32;
 
     const T* qb = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
     const T* kb_ = (const T*)p.k + (long)(b / p.kv_group) * p.k_bs + (long)h * D;
@@ -102,7 +113,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             vreg[i][1] = *(const uint4*)(vb + (long)r1 * p.v_rs + c8 * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        T* k_lds = k_lds2[buf];
+        T* vt_lds = vt_lds2[buf];
 #pragma unroll
         for (int i = 0; i < KLD; ++i) {
             const int c = tid + i * NT;
@@ -116,25 +129,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             if (c < VIT) {
                 const uint32_t a[4] = {vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w};
                 const uint32_t bq[4] = {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w};
-                uint32_t* dst = (uint32_t*)vt_lds;      // element (d, key) at d * VP + key ; dword index /2
+                uint32_t* dst = (uint32_t*)vt_lds;
+                // position of key 2kp inside the row: within each 16-key chunk the 8 keys one lane-half consumes
+                // (C-fragment order) are made contiguous, so the PV operand is ONE 16-byte read
+                const int k0 = 2 * kp, kk = k0 & 15;
+                const int ps = (k0 & ~15) + (((kk >> 2) & 1) << 3) + (kk & 3) + ((kk >> 3) << 2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // channels 2j (low halves) and 2j+1 (high halves) of keys 2kp, 2kp+1
                     const uint32_t lo = (a[j] & 0xffffu) | (bq[j] << 16);
                     const uint32_t hi_ = (a[j] >> 16) | (bq[j] & 0xffff0000u);
-                    dst[((c8 * 8 + 2 * j) * VP + 2 * kp) >> 1] = lo;
-                    dst[((c8 * 8 + 2 * j + 1) * VP + 2 * kp) >> 1] = hi_;
+                    const int r0 = c8 * 8 + 2 * j, r1 = r0 + 1;
+                    dst[(r0 * VP + ((((ps >> 3) ^ ((r0 >> 3) ^ r0)) & 7) << 3) + (ps & 7)) >> 1] = lo;
+                    dst[(r1 * VP + ((((ps >> 3) ^ ((r1 >> 3) ^ r1)) & 7) << 3) + (ps & 7)) >> 1] = hi_;
                 }
             }
         }
     };
 
     load_tile(0);
+    store_tile(0);
+    if (ntiles > 1) load_tile(1);
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();                 // every wave is done reading the previous tile
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
+        __syncthreads();                 // tile t is visible; every wave is done with tile t-1 (buffer (t+1)&1)
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        if (t + 2 < ntiles) load_tile(t + 2);      // in flight during the whole compute phase below
+        const T* k_lds = k_lds2[t & 1];
+        const T* vt_lds = vt_lds2[t & 1];
         const int kv0 = t * KVB;
 
         // ---- S^T = K Q^T : s[kb][r] = score(query col, key kv0 + 32 kb + row(r, hi))
@@ -149,11 +170,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 s[kb] = Elem<T>::mfma32(a, qf[dc], s[kb]);
             }
         }
-        // ---- scores u (raw s, or s*scale + bias in the log2 domain when a bias is present), tile max
+        // ---- two 32-key halves, each with its own online-softmax update.  Issue order matters more than
+        //      instruction count here: the second half's QK^T MFMAs (issued above) run in the matrix pipe while the
+        //      first half's softmax runs on the VALU, and the first half's PV MFMAs run under the second half's softmax.
         const float sc = HAS_BIAS ? 1.0f : p.scale_log2;            // p = exp2(u * sc - m * sc)
-        if (HAS_BIAS) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
+            if (HAS_BIAS) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, p.Nk - 4);     // Nk % 4 == 0 (checked on the host)
@@ -164,59 +187,47 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     s[kb][4 * g + 3] = fmaf(s[kb][4 * g + 3], p.scale_log2, unpack_hi<T>(w.y) * LOG2E);
                 }
             }
-        }
-        if (kv0 + KVB > p.Nk) {                                     // only the last, partial tile masks keys
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            if (kv0 + kb * 32 + 32 > p.Nk) {                        // only a partial last half masks keys
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kv0 + kb * 32 + mfma32_row(r, hi) >= p.Nk) s[kb][r] = -INFINITY;
-        }
-        float mloc = s[0][0];
+            }
+            float mloc = s[kb][0];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            // deferred rescale: keep the old running max while this half's max exceeds it by less than
+            // RESCALE_THR (log2 units), so P <= 2^THR and the O / l rescale pass is skipped for most halves
+            if (__any(mloc * sc > m_run * sc + RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
+                m_run = m_new;
+                l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        // deferred rescale: keep the old running max while the tile max exceeds it by less than RESCALE_THR
-        // (log2 units), so P <= 2^THR and the O / l rescale pass is skipped for most tiles
-        if (__any(mloc * sc > m_run * sc + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-            m_run = m_new;
-            l_run *= alpha;
+                for (int i = 0; i < DV; ++i)
 #pragma unroll
-            for (int i = 0; i < DV; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        // ---- P = exp2(u * sc - m * sc), packed straight into MFMA B-operand order
-        const float msc = m_run * sc;
-        uint4 pf[2][2];
-        float lsum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
+            // P = exp2(u * sc - m * sc), packed straight into MFMA B-operand order
+            const float msc = m_run * sc;
             float pv[16];
+            float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -msc));
                 lsum += pv[r];
             }
-            pf[kb][0] = pack8<T>(pv);
-            pf[kb][1] = pack8<T>(pv + 8);
-        }
-        l_run += lsum;
-        // ---- O^T += V^T P^T
+            l_run += lsum;
+            const uint4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
+            // O^T += V^T P^T for this half
 #pragma unroll
-        for (int dvb = 0; dvb < DV; ++dvb) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int dvb = 0; dvb < DV; ++dvb) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const T* src = vt_lds + (dvb * 32 + col) * VP + kb * 32 + 16 * c + 4 * hi;
-                    const uint2 lo = *(const uint2*)(src);
-                    const uint2 hi2 = *(const uint2*)(src + 8);
-                    o[dvb] = Elem<T>::mfma32(make_uint4(lo.x, lo.y, hi2.x, hi2.y), pf[kb][c], o[dvb]);
+                    const int row = dvb * 32 + col;
+                    const int g = kb * 4 + 2 * c + hi;                 // 16-byte group holding this lane-half's 8 keys
+                    const uint4 vf = *(const uint4*)(vt_lds + row * VP + (((g ^ ((row >> 3) ^ row)) & 7) << 3));
+                    o[dvb] = Elem<T>::mfma32(vf, c == 0 ? pf0 : pf1, o[dvb]);
                 }
             }
         }
@@ -250,18 +261,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 template <typename T, int D, bool HAS_BIAS>
-static int launch_attn_b(const AttnParams& p, hipStream_t stream) {
-    dim3 grid(p.B * p.H, 1, 1);
-    if (p.Nq <= 32) {
-        grid.y = (p.Nq + 31) / 32;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
-    } else if (p.Nq <= 64) {
-        grid.y = (p.Nq + 63) / 64;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, HAS_BIAS>), grid, dim3(128), 0, stream, p);
-    } else {
-        grid.y = (p.Nq + 127) / 128;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+static int launch_attn_b(AttnParams p, hipStream_t stream) {
+    const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
+    p.nqt = (p.Nq + 32 * nw - 1) / (32 * nw);
+    const long nblk = (long)p.B * p.H * p.nqt;
+    if (nblk > 0x7fffffffL) {
+        im360_set_error("attn_fwd: %ld workgroups exceed the grid limit", nblk);
+        return IM360_ERR_ARG;
     }
+    dim3 grid((unsigned)nblk, 1, 1);
+    if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
+    else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, HAS_BIAS>), grid, dim3(128), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

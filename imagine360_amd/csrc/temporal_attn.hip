@@ -24,108 +24,112 @@ struct TAttnParams {
     float scale_log2;
 };
 
-// QPT query frames per thread: each K/V chunk fetched from L1 is reused for QPT queries, which cuts the
-// L1 request count (the limiter of the one-query-per-thread form) by QPT
-template <typename T, int FMAX, int QPT>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnParams p) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= p.total) return;
-    const int ngrp = (p.F + QPT - 1) / QPT;
-    const int h = (int)(gid % p.heads);
-    long r = gid / p.heads;
-    const int ig = (int)(r % ngrp);
-    r /= ngrp;
-    const int px = (int)(r % p.P);
-    const int b = (int)(r / p.P);
-    const int d = p.d, nch = d >> 3;
-    const T* qp = (const T*)p.q + (long)b * p.q_bs + (long)px * p.q_ps + (long)h * d;
-    const T* kp = (const T*)p.k + (long)b * p.k_bs + (long)px * p.k_ps + (long)h * d;
-    const T* vp = (const T*)p.v + (long)b * p.v_bs + (long)px * p.v_ps + (long)h * d;
-    T* op = (T*)p.out + (long)b * p.o_bs + (long)px * p.o_ps + (long)h * d;
-    int qi[QPT];
+// One workgroup = PPB pixels x F frames x heads threads (one query row per thread).  The K and V rows of a
+// pixel (F x C each, contiguous 2C-element spans of the fused QKV rows) are staged ONCE into LDS with
+// coalesced 16-byte loads issued back to back (deep memory-level parallelism), then every thread reads its
+// head's K/V chunks from LDS (threads of one head read the same address -> broadcast).  HBM sees q, k, v, o
+// exactly once; the scores never leave registers.
+template <typename T, int FMAX>
+__global__ __launch_bounds__(512) void temporal_attn_lds_kernel(TAttnParams p, int ppb, int hpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* kv = (T*)smem;                                   // [ppb][F][k | v][hpb * d]
+    const int F = p.F, d = p.d;
+    const int G = hpb * d;                              // channels of this block's head group
+    const int h0 = blockIdx.y * hpb;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const long pix0 = (long)blockIdx.x * ppb;           // flattened (b, pixel)
+    const long npix = (long)p.total;                    // B * P
+    // ---- stage K and V of the head group: chunk id -> (pixel, frame, k|v, 16-byte chunk)
+    const int cpr = G >> 3;
+    const int nchunks = ppb * F * 2 * cpr;
+    for (int c = tid; c < nchunks; c += nthr) {
+        const int ch = c % cpr;
+        const int kvsel = (c / cpr) & 1;
+        const int f = (c / (2 * cpr)) % F;
+        const int pl = c / (2 * cpr * F);
+        const long pix = min(pix0 + pl, npix - 1);
+        const long b = pix / p.P, px = pix % p.P;
+        const T* base = kvsel ? (const T*)p.v + b * p.v_bs + px * p.v_ps + (long)f * p.v_fs
+                              : (const T*)p.k + b * p.k_bs + px * p.k_ps + (long)f * p.k_fs;
+        *(uint4*)(kv + (long)c * 8) = *(const uint4*)(base + h0 * d + ch * 8);
+    }
+    __syncthreads();
+    // ---- one query row per thread: tid -> (pixel, frame i, head), head fastest
+    const int hl = tid % hpb;
+    const int i = (tid / hpb) % F;
+    const int pl = tid / (hpb * F);
+    const long pix = pix0 + pl;
+    if (pl >= ppb || pix >= npix) return;
+    const long b = pix / p.P, px = pix % p.P;
+    const int nch = d >> 3;
+    const T* qp = (const T*)p.q + b * p.q_bs + px * p.q_ps + (long)i * p.q_fs + (long)(h0 + hl) * d;
+    T* op = (T*)p.out + b * p.o_bs + px * p.o_ps + (long)i * p.o_fs + (long)(h0 + hl) * d;
+    const T* kl = kv + (long)pl * F * 2 * G + hl * d;   // + j * 2G (+ G for V)
+    float s[FMAX];
 #pragma unroll
-    for (int t = 0; t < QPT; ++t) qi[t] = min(ig * QPT + t, p.F - 1);      // clamped duplicates are not stored
-
-    float s[QPT][FMAX];
-#pragma unroll
-    for (int t = 0; t < QPT; ++t)
-#pragma unroll
-        for (int j = 0; j < FMAX; ++j) s[t][j] = 0.f;
+    for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
     for (int c = 0; c < nch; ++c) {
-        float qf[QPT][8];
-#pragma unroll
-        for (int t = 0; t < QPT; ++t) unpack8<T>(*(const uint4*)(qp + (long)qi[t] * p.q_fs + c * 8), qf[t]);
+        float qf[8];
+        unpack8<T>(*(const uint4*)(qp + c * 8), qf);
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
-            // unconditional load of a clamped frame: a predicated load here makes hipcc branch around every load
-            // and drain vmcnt per element (dependent L2 round trips); frames >= F are masked to -inf below
             float kf[8];
-            unpack8<T>(*(const uint4*)(kp + (long)min(j, p.F - 1) * p.k_fs + c * 8), kf);
+            unpack8<T>(*(const uint4*)(kl + (long)min(j, F - 1) * 2 * G + c * 8), kf);
+            float acc = s[j];
 #pragma unroll
-            for (int t = 0; t < QPT; ++t) {
-                float acc = s[t][j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(qf[t][e], kf[e], acc);
-                s[t][j] = acc;
-            }
+            for (int e = 0; e < 8; ++e) acc = fmaf(qf[e], kf[e], acc);
+            s[j] = acc;
         }
     }
-    float inv[QPT];
+    float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < QPT; ++t) {
-        float m = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            s[t][j] = (j < p.F) ? s[t][j] * p.scale_log2 : -INFINITY;
-            m = fmaxf(m, s[t][j]);
-        }
-        float l = 0.f;
-#pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            s[t][j] = __builtin_amdgcn_exp2f(s[t][j] - m);
-            l += s[t][j];
-        }
-        inv[t] = 1.0f / l;
+    for (int j = 0; j < FMAX; ++j) {
+        s[j] = (j < F) ? s[j] * p.scale_log2 : -INFINITY;
+        m = fmaxf(m, s[j]);
     }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) {
+        s[j] = __builtin_amdgcn_exp2f(s[j] - m);
+        l += s[j];
+    }
+    const float inv = 1.0f / l;
     for (int c = 0; c < nch; ++c) {
-        float of[QPT][8];
-#pragma unroll
-        for (int t = 0; t < QPT; ++t)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) of[t][e] = 0.f;
+        float of[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < FMAX; ++j) {
-            float vf[8];                                    // frames >= F carry probability exactly 0
-            unpack8<T>(*(const uint4*)(vp + (long)min(j, p.F - 1) * p.v_fs + c * 8), vf);
+            float vf[8];
+            unpack8<T>(*(const uint4*)(kl + (long)min(j, F - 1) * 2 * G + G + c * 8), vf);
 #pragma unroll
-            for (int t = 0; t < QPT; ++t)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) of[t][e] = fmaf(s[t][j], vf[e], of[t][e]);
+            for (int e = 0; e < 8; ++e) of[e] = fmaf(s[j], vf[e], of[e]);
         }
 #pragma unroll
-        for (int t = 0; t < QPT; ++t) {
-            if (ig * QPT + t < p.F) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) of[t][e] *= inv[t];
-                *(uint4*)(op + (long)qi[t] * p.o_fs + c * 8) = pack8<T>(of[t]);
-            }
-        }
+        for (int e = 0; e < 8; ++e) of[e] *= inv;
+        *(uint4*)(op + c * 8) = pack8<T>(of);
     }
 }
 
-template <typename T, int FMAX, int QPT>
+template <typename T, int FMAX>
 static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
-    const long ngrp = (p.F + QPT - 1) / QPT;
-    p.total = (long)(p.total / p.F) * ngrp;          // B * P * heads * query groups
-    const long blocks = (p.total + 255) / 256;
-    hipLaunchKernelGGL((temporal_attn_kernel<T, FMAX, QPT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    const long npix = p.total / ((long)p.F * p.heads);                 // B * P
+    int hpb = p.heads;                                                  // heads per block: keep one pixel's K|V <= 48 KiB
+    while (hpb > 1 && (hpb % 2) == 0 && ((long)p.F * 2 * hpb * p.d * sizeof(T) > 48 * 1024 || p.F * hpb > 512)) hpb /= 2;
+    const long bytes_per_pix = (long)p.F * 2 * hpb * p.d * sizeof(T);
+    const int per_pix_threads = p.F * hpb;
+    int ppb = 256 / per_pix_threads;
+    if (ppb < 1) ppb = 1;
+    while (ppb > 1 && ppb * bytes_per_pix > 48 * 1024) --ppb;
+    const int threads = ((ppb * per_pix_threads + 63) / 64) * 64;
+    p.total = npix;
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb), (unsigned)(p.heads / hpb));
+    hipLaunchKernelGGL((temporal_attn_lds_kernel<T, FMAX>), grid, dim3(threads), (size_t)(ppb * bytes_per_pix), stream, p, ppb, hpb);
 }
 
 template <typename T>
 static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
-    if (p.F <= 16) launch_tattn_v<T, 16, 4>(p, stream);
-    else if (p.F <= 32) launch_tattn_v<T, 32, 2>(p, stream);
-    else launch_tattn_v<T, 64, 1>(p, stream);
+    if (p.F <= 16) launch_tattn_v<T, 16>(p, stream);
+    else if (p.F <= 32) launch_tattn_v<T, 32>(p, stream);
+    else launch_tattn_v<T, 64>(p, stream);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
@@ -153,7 +157,7 @@ extern "C" int im360_temporal_attn_fwd(const void* q, const void* k, const void*
     p.q_fs = p.k_fs = p.v_fs = qkv_fs; p.q_ps = p.k_ps = p.v_ps = qkv_ps; p.q_bs = p.k_bs = p.v_bs = qkv_bs;
     p.o_fs = o_fs; p.o_ps = o_ps; p.o_bs = o_bs;
     p.scale_log2 = scale * 1.4426950408889634f;
-    IM360_CHECK_ARG((p.total + 255) / 256 <= 0x7fffffffL, "temporal_attn_fwd: problem too large");
+    IM360_CHECK_ARG(F * 2 * d * 2 <= 48 * 1024, "temporal_attn_fwd: one head's K|V rows (%ld frames x %ld) exceed the LDS budget", (long)F, (long)d);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_TEMPORAL, stream);
     if (dtype == 0) return launch_tattn<__bf16>(p, s);

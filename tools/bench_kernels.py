@@ -99,13 +99,30 @@ def bench_gn(iters):
               f"{2 * by / t2 / 1e9:6.0f} GB/s")
 
 
+def bench_linear(iters):
+    """torch F.linear (hipBLASLt) vs the implicit-GEMM kernel used as a 1x1 conv on the same shapes."""
+    import torch.nn.functional as F
+    shapes = [("pers L0 qkv", 655360, 320, 960), ("pers L0 ff-in", 655360, 320, 2560), ("pers L0 ff-out", 655360, 1280, 320),
+              ("pers L0 proj", 655360, 320, 320), ("pers L1 qkv", 163840, 640, 1920), ("pers L1 ff-in", 163840, 640, 5120),
+              ("pers L1 ff-out", 163840, 2560, 640), ("pers L2 ff-in", 40960, 1280, 10240), ("pers L2 ff-out", 40960, 5120, 1280),
+              ("pano L0 ff-in", 262144, 320, 2560)]
+    for name, M, Kd, N in shapes:
+        x, w, b = rn(M, Kd), rn(N, Kd) * Kd ** -0.5, rn(N)
+        t1 = timeit(lambda: F.linear(x, w, b), iters)
+        wp = K.pack_conv_weight(w.reshape(N, Kd, 1, 1))
+        x4 = x.reshape(M // 64, 8, 8, Kd)
+        t2 = timeit(lambda: K.conv2d(x4, wp, N, bias=b), iters)
+        fl = 2.0 * M * Kd * N
+        print(f"linear {name:16s} M={M:6d} K={Kd:4d} N={N:5d}: torch {t1 * 1e3:7.3f} ms {fl / t1 / 1e12:6.0f} TF/s | im360 1x1 {t2 * 1e3:7.3f} ms {fl / t2 / 1e12:6.0f} TF/s")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 10
     if "--iters" in sys.argv:
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
         args = [a for a in args if a != str(iters)]
-    which = args or ["attn", "conv", "temporal", "ln", "gn"]
+    which = args or ["attn", "conv", "temporal", "ln", "gn", "linear"]
     torch.set_grad_enabled(False)
     for w in which:
         globals()["bench_" + w](iters)
