@@ -47,7 +47,20 @@ def cpu_baseline(args):
     from imagine360_amd.mv_model import MultiViewBaseModel
     from imagine360_amd.weights import filler_tensor
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # give the CPU its best shot: pick the thread count that maximises fp32 GEMM throughput on this host
+    # (oversubscribing a 256-thread box makes the small per-frame ops of this path 3x slower)
+    best, best_t = cores, 0.0
+    a, bm = torch.randn(4096, 1280), torch.randn(1280, 1280)
+    for nt in sorted({min(cores, c) for c in (16, 32, 64, 128, cores)}):
+        torch.set_num_threads(nt)
+        torch.mm(a, bm)
+        t0 = time.time()
+        for _ in range(5):
+            torch.mm(a, bm)
+        r = 1.0 / (time.time() - t0)
+        if r > best_t:
+            best, best_t = nt, r
+    torch.set_num_threads(best)
     with torch.device("meta"):
         meta = MultiViewBaseModel(configs.build_unet(1), configs.build_unet(1)).state_dict()
     frames, ctx_n, views = 8, 141, 12
@@ -92,6 +105,7 @@ def main():
     ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +143,7 @@ def main():
     pers_lat = pers_in[:1, :, :4].contiguous()
     guidance = 7.5
 
-    def step(i):
+    def eager_step(i):
         nonlocal pano_lat, pers_lat
         t = i % nsteps_total
         pano_in[:, :4] = pano_lat
@@ -145,29 +159,55 @@ def main():
         pano_lat = sch.fused_cfg_step(pred_pano[0:1], pred_pano[1:2], guidance, ts_host[t], pano_lat)
         pers_lat = sch.fused_cfg_step(pred_pers[0:1], pred_pers[1:2], guidance, ts_host[t], pers_lat)
 
+    step = eager_step
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    prof_kinds = ["conv", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
+    graphed = None
+    if not args.no_graph:
+        # the step is ~3000 launches: capture it once (hipGraph) and replay, so the host is out of the loop
+        from imagine360_amd.graph_step import GraphedDenoiseStep
+        graphed = GraphedDenoiseStep(mv, sch, inp, cams, pano_lat, pers_lat, guidance, warmup=1)
+
+        def step(i):                                                       # noqa: F811
+            graphed.step(ts_host[i % nsteps_total])
+
     for i in range(args.warmup):
         step(i)
-    prof_kinds = ["conv", "attn", "temporal", "gn_stats", "gn_apply"]
-    kernels.prof_enable(prof_kinds)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if graphed is not None:
+        pano_lat = graphed.pano_lat
     if dist is not None:          # latent boundary: gather every rank's panorama latent (1 MB each)
         gathered = [torch.empty_like(pano_lat) for _ in range(world)]
         dist.all_gather(gathered, pano_lat)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernels.prof_enable([])
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # per-kernel-class durations: the same K steps once more, issued eagerly with HIP events around every launch
+    # of our kernels (a graph replay has no per-launch host hook); kernel durations do not depend on how they were launched
+    if rank == 0:
+        if graphed is not None:
+            pano_lat, pers_lat = graphed.pano_lat.clone(), graphed.pers_lat.clone()
+
+            def step(i):                                                   # noqa: F811
+                eager_step(i)
+        kernels.prof_enable(prof_kinds)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        eager_elapsed = time.perf_counter() - t1
+        kernels.prof_enable([])
     finite = bool(torch.isfinite(pano_lat.float()).all().item())
 
     if rank == 0:
@@ -187,6 +227,8 @@ def main():
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "launch": "eager" if graphed is None else "hipGraph replay (one captured step)",
+            "eager_ms_per_step": 1e3 * eager_elapsed / args.steps,
             "config": {"workload": w["desc"], "parallelism": f"sample-parallel x{world}" if world > 1 else "single GPU",
                        "width_div": args.width_div, "ddim_steps_schedule": nsteps_total, "guidance": guidance,
                        "tflop_per_step": total / 1e12, "outputs_finite": finite},

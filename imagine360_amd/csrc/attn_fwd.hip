@@ -22,6 +22,7 @@ namespace im360 {
 
 struct AttnParams {
     const void* q; const void* k; const void* v; const void* bias; void* out;
+    const void* bias_alt; const int* bias_sel;     // *bias_sel != 0 -> use bias_alt (decided on the device: graph-replay safe)
     int B, H, Nq, Nk;
     int nqt;             // query tiles per (batch, head)
     int kv_group;        // K/V batch index = query batch index / kv_group (context shared by the frames of a video)
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const T* kb_ = (const T*)p.k + (long)(b / p.kv_group) * p.k_bs + (long)h * D;
     const T* vb = (const T*)p.v + (long)(b / p.kv_group) * p.v_bs + (long)h * D;
     const T* bias = (const T*)p.bias;
+    if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) bias = (const T*)p.bias_alt;
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 dc + 8 hi .. +7]
     int qrow = q0 + col;
@@ -288,7 +290,8 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
                               int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                               int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
-                              int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream) {
+                              int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
+                              const void* bias_alt, const void* bias_sel) {
     using namespace im360;
     IM360_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
     IM360_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attn_fwd: empty problem B=%ld H=%ld Nq=%ld Nk=%ld",
@@ -307,6 +310,8 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     }
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.out = out;
+    p.bias_alt = bias_alt; p.bias_sel = (const int*)bias_sel;
+    IM360_CHECK_ARG(!bias_sel || (bias && bias_alt && ((uintptr_t)bias_alt % 8) == 0), "attn_fwd: bias_sel needs bias and an aligned bias_alt");
     p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;

@@ -161,7 +161,12 @@ __global__ void circular_pad_w_kernel(const T* __restrict__ x, T* __restrict__ y
 //      v = u + g (c - u);  x_prev = cx * x + cv * v   with cx, cv precomputed on the host in fp64
 template <typename T>
 __global__ void cfg_ddim_kernel(const T* __restrict__ uncond, const T* __restrict__ cond, const T* __restrict__ x,
-                                T* __restrict__ out, long n8, float g, float cx, float cv) {
+                                T* __restrict__ out, long n8, float g, float cx, float cv, const float* __restrict__ coef) {
+    if (coef != nullptr) {          // (guidance, cx, cv) read on the device: the launch can be replayed from a hipGraph
+        g = coef[0];
+        cx = coef[1];
+        cv = coef[2];
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         float u[8], c[8], s[8];
         unpack8<T>(((const uint4*)uncond)[i], u);
@@ -268,7 +273,7 @@ extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_
 
 // out = cx * x + cv * (uncond + g (cond - uncond)), n elements (n % 8 == 0), all same dtype
 extern "C" int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
-                                     float guidance, float cx, float cv, int dtype, void* stream) {
+                                     float guidance, float cx, float cv, int dtype, void* stream, const void* coef_dev) {
     using namespace im360;
     IM360_CHECK_ARG(uncond && cond && x && out, "cfg_ddim_update: null pointer");
     IM360_CHECK_ARG(n > 0 && (n % 8) == 0, "cfg_ddim_update: n=%ld must be a positive multiple of 8", (long)n);
@@ -279,10 +284,10 @@ extern "C" int im360_cfg_ddim_update(const void* uncond, const void* cond, const
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
         hipLaunchKernelGGL((cfg_ddim_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)uncond,
-                           (const __bf16*)cond, (const __bf16*)x, (__bf16*)out, n8, guidance, cx, cv);
+                           (const __bf16*)cond, (const __bf16*)x, (__bf16*)out, n8, guidance, cx, cv, (const float*)coef_dev);
     else if (dtype == 1)
         hipLaunchKernelGGL((cfg_ddim_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)uncond,
-                           (const _Float16*)cond, (const _Float16*)x, (_Float16*)out, n8, guidance, cx, cv);
+                           (const _Float16*)cond, (const _Float16*)x, (_Float16*)out, n8, guidance, cx, cv, (const float*)coef_dev);
     else {
         im360_set_error("cfg_ddim_update: dtype %d unsupported", dtype);
         return IM360_ERR_UNSUPPORTED;

@@ -17,7 +17,7 @@ _I64, _F32, _INT, _PTR = ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_
 _SIGNATURES = {
     "im360_abi_version": (_INT, []),
     "im360_last_error": (ctypes.c_char_p, []),
-    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR]),
+    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR]),
     "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
@@ -25,7 +25,7 @@ _SIGNATURES = {
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
-    "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR]),
+    "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR, _PTR]),
     "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
     "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
     "im360_prof_enable": (None, [ctypes.c_uint]),
@@ -83,9 +83,11 @@ def _p(t):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1):
+def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
+              bias_alt=None, bias_sel=None):
     """q [B, Nq, heads*d], k/v [B / kv_group, Nk, heads*d] (last dim contiguous, any row/batch stride),
-    bias [Nq, Nk] shared by every (batch, head).  Returns out [B, Nq, heads*d]."""
+    bias [Nq, Nk] shared by every (batch, head); with ``bias_sel`` (device int32 scalar) the kernel picks
+    ``bias_alt`` when it is non-zero.  Returns out [B, Nq, heads*d]."""
     _dev(q, k, v, bias, out)
     B, Nq, C = q.shape
     Nk = k.shape[1]
@@ -103,7 +105,7 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
     rc = lib().im360_attn_fwd(_p(q), _p(k), _p(v), _p(bias), _p(out), B, heads, Nq, Nk, d,
                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                               out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0, kv_group,
-                              float(scale), float(out_scale), int(accumulate), _dt(q), _stream())
+                              float(scale), float(out_scale), int(accumulate), _dt(q), _stream(), _p(bias_alt), _p(bias_sel))
     _check(rc, "im360_attn_fwd")
     return out
 
@@ -239,14 +241,15 @@ def circular_pad_w(x, pad):
     return y
 
 
-def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv):
-    """x_prev = cx * sample + cv * (uncond + guidance * (cond - uncond))."""
+def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
+    """x_prev = cx * sample + cv * (uncond + guidance * (cond - uncond)); ``coef_dev`` = device float32[3]
+    (guidance, cx, cv) read by the kernel instead of the scalars (graph replay)."""
     _dev(uncond, cond, sample)
     assert uncond.is_contiguous() and cond.is_contiguous() and sample.is_contiguous()
     assert uncond.shape == cond.shape == sample.shape and uncond.dtype == sample.dtype
     out = torch.empty_like(sample)
     rc = lib().im360_cfg_ddim_update(_p(uncond), _p(cond), _p(sample), _p(out), sample.numel(),
-                                     float(guidance), float(cx), float(cv), _dt(sample), _stream())
+                                     float(guidance), float(cx), float(cv), _dt(sample), _stream(), _p(coef_dev))
     _check(rc, "im360_cfg_ddim_update")
     return out
 

@@ -78,16 +78,23 @@ class WarpAttn(nn.Module):
                 self._geom[key] = (b_e2p.to(dtype), b_p2e.to(dtype), pers_pe.to(dtype), equi_pe.to(dtype))
         return self._geom[key]
 
-    def forward_cl(self, pers, equi, cameras, frames, opposite=None):
-        """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes."""
+    def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None):
+        """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes.  ``sel``: device int32
+        scalar holding the normal (0) / antipodal (1) mask choice; then both variants are handed to the kernel and
+        the choice is made on the device, which keeps the whole denoising step replayable from a hipGraph."""
         t = self.transformer
         nf, ph, pw, c = pers.shape
         ne_img, eh, ew, _ = equi.shape
         b = ne_img // frames
         m = nf // ne_img
-        if opposite is None:
-            opposite = random.random() < 0.4                     # the reference's coin, one draw per call
-        b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
+        alt_e2p = alt_p2e = None
+        if sel is not None:
+            b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, False, pers.device, pers.dtype)
+            alt_e2p, alt_p2e, _, _ = self.geometry(ph, pw, eh, ew, cameras, True, pers.device, pers.dtype)
+        else:
+            if opposite is None:
+                opposite = random.random() < 0.4                 # the reference's coin, one draw per call
+            b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
         eq = equi.reshape(b * frames, eh * ew, c)
         # (b m) f (h w) c -> (b f) (m h w) c
         pr = pers.reshape(b, m, frames, ph * pw, c).permute(0, 2, 1, 3, 4).reshape(b * frames, m * ph * pw, c)
@@ -95,8 +102,8 @@ class WarpAttn(nn.Module):
         pr_n = layer_norm(t.norm1, pr, pre=pers_pe)
         qkv_e, qkv_p = t.attn1.qkv(eq_n), t.attn1.qkv(pr_n)
         h = t.attn1.heads
-        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p)
-        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e)
+        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel)
+        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel)
         eq = t.attn1.to_out(a_e) + eq
         eq = t.ff(layer_norm(t.norm2, eq)) + eq
         pr = t.attn1.to_out(a_p) + pr
@@ -129,6 +136,22 @@ class MultiViewBaseModel(nn.Module):
         self.noise_on_host = False      # True: draw the per-step IP noise from the CPU generator (CPU-reference RNG parity)
         self.taps = None                # dict -> records (pers, equi) after each WarpAttn, for tests
         self._rig_cache = {}
+        self._coins_dev = None          # int32[8] on the device: the 7 WarpAttn coins of the current step
+        self.coins_preloaded = False    # True while a captured graph replays: the driver draws + uploads the coins
+
+    def draw_coins(self, device):
+        """The reference draws ``random.random() < 0.4`` once per WarpAttn call (src/utils/utils.py:15), 7 per step in
+        execution order enc0..2, mid, dec0..2; nothing else consumes Python's RNG in between, so drawing the 7 up
+        front keeps the stream identical.  They go to a small device tensor the attention kernels read."""
+        if self._coins_dev is None or self._coins_dev.device != torch.device(device):
+            self._coins_dev = torch.zeros(8, dtype=torch.int32, device=device)
+            self._coins_host = torch.zeros(8, dtype=torch.int32)
+            if torch.device(device).type == "cuda":
+                self._coins_host = self._coins_host.pin_memory()
+        for i in range(7):
+            self._coins_host[i] = 1 if random.random() < 0.4 else 0
+        self._coins_dev.copy_(self._coins_host, non_blocking=True)
+        return self._coins_dev
 
     def _rig(self, cameras, m):
         """Camera dict flattened to [m, ...] plus host-side FoV/theta/phi lists, cached so a denoising loop
@@ -194,9 +217,11 @@ class MultiViewBaseModel(nn.Module):
 
         pano = self.pano_pad
         taps = self.taps
+        coins = self._coins_dev if self.coins_preloaded else self.draw_coins(x.device)
+        order = {"enc0": 0, "enc1": 1, "enc2": 2, "mid": 3, "dec0": 4, "dec1": 5, "dec2": 6}
 
         def warp(blk, name, a, e):
-            a, e = blk.forward_cl(a, e, cams, f)
+            a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]])
             if taps is not None:
                 taps[name] = (a, e)
             return a, e

@@ -99,8 +99,9 @@ class DDIMScheduler:
         prev = cx * sample + cv * model_output
         return DDIMSchedulerOutput(prev_sample=prev.to(sample.dtype)) if return_dict else (prev,)
 
-    def fused_cfg_step(self, pred_uncond, pred_text, guidance_scale, timestep, sample):
-        """CFG combine + update in one HIP kernel (pipeline_animation_inference_dual.py:791-800)."""
-        cx, cv = self.coefficients(timestep)
+    def fused_cfg_step(self, pred_uncond, pred_text, guidance_scale, timestep, sample, coef_dev=None):
+        """CFG combine + update in one HIP kernel (pipeline_animation_inference_dual.py:791-800).  ``coef_dev``:
+        device float32[3] (guidance, cx, cv) read by the kernel instead of host scalars (graph replay)."""
+        cx, cv = (0.0, 0.0) if coef_dev is not None else self.coefficients(timestep)
         return kernels.cfg_ddim_update(pred_uncond.contiguous(), pred_text.contiguous(), sample.contiguous(),
-                                       guidance_scale, cx, cv)
+                                       guidance_scale, cx, cv, coef_dev=coef_dev)

@@ -22,6 +22,8 @@ const char* im360_last_error(void);
 /* softmax(Q K^T * scale + bias) V, head dim D in {32, 64}; head h of batch b lives at
  * base + b*bs + row*rs + h*D.  bias (optional) is ONE [Nq, Nk] matrix shared by all (b, h).
  * accumulate != 0: out += out_scale * result (second KV set of the IP cross attention).
+ * bias_alt / bias_sel (optional): a second [Nq, Nk] bias and a device int32; the kernel uses bias_alt when
+ *   *bias_sel != 0 (WarpAttn's normal / antipodal mask choice made on the device, so a step can be graph-replayed).
  * kv_group: K/V batch index = query batch index / kv_group (one context per video, F frames of queries).
  * Replaces: xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
  *   diffusers/models/attention_processor.py:1264, 1351, 641 (spatial self / cross attention),
@@ -31,7 +33,8 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                    int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
-                   int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream);
+                   int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
+                   const void* bias_alt, const void* bias_sel);
 
 /* Temporal self-attention over F <= 64 frames on token-major activations [B, F, P, heads*d]
  * (q, k, v are three views with common strides, e.g. slices of a fused QKV projection).
@@ -85,11 +88,12 @@ int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, 
 int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
                          int dtype, void* stream);
 
-/* out = cx * x + cv * (uncond + guidance * (cond - uncond)); cx, cv = DDIM v-prediction coefficients.
+/* out = cx * x + cv * (uncond + guidance * (cond - uncond)); cx, cv = DDIM v-prediction coefficients;
+ * coef_dev (optional): device float[3] = (guidance, cx, cv) overriding the scalars (hipGraph replay).
  * Replaces: the CFG combine + DDIMScheduler.step elementwise chain,
  *   pipeline_animation_inference_dual.py:791-800; diffusers/schedulers/scheduling_ddim.py:300-350. */
 int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
-                          float guidance, float cx, float cv, int dtype, void* stream);
+                          float guidance, float cx, float cv, int dtype, void* stream, const void* coef_dev);
 
 /* y[r] = LayerNorm(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod] on token rows
  * [rows, C]; pre / post are optional [*, C] tables (the WarpAttn spherical PE added before norm1, the motion

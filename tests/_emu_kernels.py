@@ -12,7 +12,10 @@ import torch
 import torch.nn.functional as F
 
 
-def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1):
+def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
+              bias_alt=None, bias_sel=None):
+    if bias_sel is not None and int(bias_sel) != 0:
+        bias = bias_alt
     B, Nq, C = q.shape
     d = C // heads
     if kv_group > 1:
@@ -110,7 +113,9 @@ def circular_pad_w(x, pad):
     return torch.cat([x[..., -pad:, :], x, x[..., :pad, :]], dim=-2).contiguous()
 
 
-def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv):
+def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
+    if coef_dev is not None:
+        guidance, cx, cv = (float(x) for x in coef_dev)
     return (cx * sample.float() + cv * (uncond.float() + guidance * (cond.float() - uncond.float()))).to(sample.dtype)
 
 
