@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="hipBLASLt default heuristic instead of the shipped solution table")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -127,6 +128,10 @@ def main():
     w = WORKLOADS[args.workload]
     torch.set_grad_enabled(False)
     kernels.lib()
+    tuned = False
+    if not args.no_tuned_gemms:
+        from imagine360_amd import tuning
+        tuned = tuning.enable()
     mv = configs.build_mv_model(args.width_div, device=dev, dtype=dt, xformers=True)
     inp = synthetic.mv_inputs(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=1 + rank,
                               sam_frames=max(16, w["frames"]), dtype=dt, device=dev)
@@ -227,6 +232,7 @@ def main():
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "tuned_gemm_table": tuned,
             "launch": "eager" if graphed is None else "hipGraph replay (one captured step)",
             "eager_ms_per_step": 1e3 * eager_elapsed / args.steps,
             "config": {"workload": w["desc"], "parallelism": f"sample-parallel x{world}" if world > 1 else "single GPU",
