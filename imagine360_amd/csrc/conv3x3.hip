@@ -35,23 +35,27 @@ struct ConvParams {
     long nblocks;
 };
 
-constexpr int BM = 128, BN = 128;
 
 // 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
 __device__ uint4 g_zero_chunk[1];
 
-template <typename T, int BK>
+// WM x WN waves of 64 x 64 outputs each: (2, 2) = 128 pixels x 128 couts; (4, 1) = 256 pixels x 64 couts, used when
+// Cout leaves a half-empty last 128-tile (Cout = 320: 5 exact 64-tiles instead of 3 x 128 = 17 % padded MFMA work)
+template <typename T, int BK, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
     constexpr int ROWB = BK * 2;                // bytes per tile row
     constexpr int RPB = 256 / ROWB;             // tile rows per 256-byte LDS bank row
-    constexpr int LD = (128 * CPR) / 256;       // LDS-DMA loads per thread per operand per K-step
+    constexpr int LDA = (BM * CPR) / 256;       // LDS-DMA loads per thread per K-step: activations
+    constexpr int LDB = (BN * CPR) / 256;       //                                         weights
     constexpr int KC = BK / 16;
-    constexpr int TILE = 128 * ROWB;            // bytes of one operand tile
+    constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB;     // bytes of the operand tiles
+    constexpr int STAGE = TILE_A + TILE_B;
     // [buffer][A | B]: unpadded row-major tiles written by global_load_lds (lane-linear destination), the
     // 16-byte chunk position XOR-swizzled with the row so MFMA fragment reads (16 rows, one K chunk) hit 16
     // different slots of the 256-byte bank row
-    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE];
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
     long bid = blockIdx.x;
@@ -66,21 +70,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, hi = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int Hc = p.up ? 2 * p.Hin : p.Hin, Wc = p.up ? 2 * p.Win : p.Win;
     const T* xg = (const T*)p.x;
     const T* wg = (const T*)p.w;
     const T* zero = (const T*)g_zero_chunk;
 
     // per-thread staging slots: chunk c = i * 256 + tid -> tile row c / CPR, LDS position c % CPR
-    int pn[LD], py[LD], pxx[LD], pd8[LD], prow[LD];
-    bool pvalid[LD];
+    int pn[LDA], py[LDA], pxx[LDA], pd8[LDA];
+    bool pvalid[LDA];
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
+    for (int i = 0; i < LDA; ++i) {
         const int c = tid + i * 256;
-        prow[i] = c / CPR;
-        pd8[i] = ((c % CPR) ^ ((prow[i] / RPB) & (CPR - 1))) * 8;      // data chunk (elements) stored at this position
-        const long m = m0 + prow[i];
+        const int row = c / CPR;
+        pd8[i] = ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;          // data chunk (elements) stored at this position
+        const long m = m0 + row;
         pvalid[i] = m < p.M;
         const long mm = pvalid[i] ? m : 0;
         pxx[i] = (int)(mm % p.Wout);
@@ -103,16 +107,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
     // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
     // steps; the packed weights [cout][tap][cin] are contiguous across taps, so their pointers just keep advancing.
-    const T* aptr[LD];
-    const T* bptr[LD];
-    int ainc[LD];
+    const T* aptr[LDA];
+    const T* bptr[LDB];
+    int ainc[LDA];
 #pragma unroll
-    for (int i = 0; i < LD; ++i) bptr[i] = wg + (long)(n0 + prow[i]) * p.ntaps * p.Cin + pd8[i];
+    for (int i = 0; i < LDB; ++i) {
+        const int c = tid + i * 256, row = c / CPR;
+        bptr[i] = wg + (long)(n0 + row) * p.ntaps * p.Cin + ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;
+    }
     int tap_p = 0, kk_p = 0;
     auto set_tap = [&](int tap) {
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {
+        for (int i = 0; i < LDA; ++i) {
             int gy = py[i] * p.stride + dy - 1 + p.y_off;
             int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
             bool ok = pvalid[i] && gy >= 0 && gy < Hc;
@@ -131,15 +138,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
 
     auto stage = [&](int buf) {
-        char* abase = lds + buf * 2 * TILE + wid_s * 1024;
-        char* bbase = abase + TILE;
+        char* abase = lds + buf * STAGE + wid_s * 1024;
+        char* bbase = abase + TILE_A;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {
+        for (int i = 0; i < LDA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
                                              (__attribute__((address_space(3))) void*)(abase + i * 4096), 16, 0, 0);
+            aptr[i] += ainc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LDB; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[i],
                                              (__attribute__((address_space(3))) void*)(bbase + i * 4096), 16, 0, 0);
-            aptr[i] += ainc[i];
             bptr[i] += BK;
         }
         if (++kk_p == ksteps_per_tap) {
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
         if (s + 1 < nsteps) stage((s + 1) & 1);
-        const char* at = lds + (s & 1) * 2 * TILE;
-        const char* bt = at + TILE;
+        const char* at = lds + (s & 1) * STAGE;
+        const char* bt = at + TILE_A;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             uint4 wf[2], xf[2];
@@ -237,14 +247,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
 }
 
-template <typename T>
-static int launch_conv(const ConvParams& p, hipStream_t stream) {
+template <typename T, int WM, int WN>
+static int launch_conv_t(ConvParams p, hipStream_t stream) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (p.nblocks > 0x7fffffffL) {
+        im360_set_error("conv_fwd: problem too large");
+        return IM360_ERR_ARG;
+    }
     if (p.Cin % 64 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 32>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
+}
+
+template <typename T>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+    // a last 128-wide cout tile that is at most half full wastes MFMA work: use 256 x 64 tiles instead
+    const int rem = p.Cout % 128;
+    if (rem != 0 && rem <= 64 && p.Cout > 64) return launch_conv_t<T, 4, 1>(p, stream);
+    return launch_conv_t<T, 2, 2>(p, stream);
 }
 
 // weights [Cout, Cin, kh, kw] (PyTorch) -> [CoutPad128][kh*kw][CinPad] zero padded, K contiguous
@@ -288,9 +313,6 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     p.stride = (int)stride; p.up = up ? 1 : 0; p.wrap = wrap ? 1 : 0; p.x_off = (int)x_off; p.y_off = (int)y_off;
     p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
     p.M = N * Hout * Wout;
-    p.tiles_n = (int)((Cout + BN - 1) / BN);
-    p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
-    IM360_CHECK_ARG(p.nblocks <= 0x7fffffffL, "conv_fwd: problem too large");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_CONV, stream);
     if (dtype == 0) return launch_conv<__bf16>(p, s);

@@ -44,6 +44,7 @@ class AnimationPipeline:
             self.SAMpredictor = SamPredictor(image_encoder)
             self.SAMProcessor = self.SAMpredictor.transform
         self.rng = "device"
+        self.use_graph = True       # replay one captured hipGraph per step (device RNG only; see graph_step.py)
         self._device = None
 
     # ---- reference surface ------------------------------------------------------------------------
@@ -205,7 +206,18 @@ class AnimationPipeline:
         in_pano = torch.cat([torch.cat((pano_latent, pano_mask_l.to(dt), pano_ml.to(dt)), dim=1)] * 2)
         in_pers = torch.cat([torch.cat((pers_latent, pers_mask_l.to(dt), pers_ml.to(dt)), dim=2)] * 2)
 
+        graphed = None
+        if self.use_graph and self.rng == "device" and pano_latent.is_cuda and trace is None and callback is None:
+            from .graph_step import GraphedDenoiseStep
+            inputs = dict(latents=in_pers, pano_latent=in_pano, prompt_embd=text_pers, pano_prompt_embd=text_pano,
+                          fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers, reference_images_clip_feat_pano=feat_pano,
+                          reference_images_clip_feat_pers=feat_pers, relative_position_tensor=rel, pitchs_tensor=pitch)
+            graphed = GraphedDenoiseStep(self.mv_base_model, self.scheduler, inputs, cameras, pano_latent, pers_latent,
+                                         guidance_scale_text, use_fps=use_fps_condition)
         for i, t in enumerate(self.progress_bar(steps_host)):
+            if graphed is not None:
+                pano_latent, pers_latent = graphed.step(t)
+                continue
             in_pano[:, :4] = pano_latent
             in_pers[:, :, :4] = pers_latent
             pred_pers, pred_pano = self.mv_base_model(

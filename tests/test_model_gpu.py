@@ -142,3 +142,37 @@ def test_full_size_groupnorm_and_temporal_properties():
     # a single frame attends only to itself: temporal attention returns V
     qkv = torch.randn(2 * 1 * 8192, 3 * 320, generator=g).to(dev, dt)
     assert torch.equal(K.temporal_attention(qkv, 2, 1, 8192, 8), qkv[:, 640:])
+
+
+def test_graph_replayed_step_equals_eager_step():
+    """One captured hipGraph step replayed 3 times == 3 eagerly issued steps (IP noise switched off so both paths see
+    the same numbers; the WarpAttn coins come from Python's RNG in both)."""
+    from imagine360_amd.graph_step import GraphedDenoiseStep
+    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True)
+    mv._ip_noise = lambda like: torch.zeros_like(like)
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    sch.set_timesteps(25)
+    ts = sch._timesteps_host
+    cams = S.icosahedron_cameras(90, 128, device=dev)
+
+    def fresh():
+        inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=4, sam_frames=16, dtype=dt, device=dev)
+        return inp, inp["pano_latent"][:1, :4].contiguous(), inp["latents"][:1, :, :4].contiguous()
+
+    inp, pano, pers = fresh()
+    random.seed(5)
+    for i in range(3):
+        inp["pano_latent"][:, :4] = pano
+        inp["latents"][:, :, :4] = pers
+        pp, pn = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True,
+                    **{**inp, "timestep": torch.tensor([ts[i]], device=dev)})
+        pano = sch.fused_cfg_step(pn[0:1], pn[1:2], 7.5, ts[i], pano)
+        pers = sch.fused_cfg_step(pp[0:1], pp[1:2], 7.5, ts[i], pers)
+    inp2, pano2, pers2 = fresh()
+    inp2.pop("timestep")
+    g = GraphedDenoiseStep(mv, sch, inp2, cams, pano2, pers2, 7.5)      # consumes 7 Python draws while warming up
+    random.seed(5)
+    for i in range(3):
+        g.step(ts[i])
+    assert rel(g.pano_lat, pano) < 1e-6 and rel(g.pers_lat, pers) < 1e-6
