@@ -15,12 +15,12 @@ class GraphedDenoiseStep:
         ``pano_latent`` [1,4,F,H,W] / ``pers_latent`` [1,m,4,F,h,w]: initial noisy latents."""
         self.mv, self.sch, self.inp, self.cams, self.g = mv, scheduler, inputs, cameras, float(guidance)
         dev = pano_latent.device
-        self.pano_lat = pano_latent.clone()
-        self.pers_lat = pers_latent.clone()
+        # private copies: the caller's tensors may alias the model-input buffers the body writes into
+        init_pano, init_pers = pano_latent.clone(), pers_latent.clone()
+        self.pano_lat = init_pano.clone()
+        self.pers_lat = init_pers.clone()
         self.timestep = torch.zeros(1, dtype=torch.int64, device=dev)
         self.coef = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._t_host = torch.zeros(1, dtype=torch.int64).pin_memory()
-        self._coef_host = torch.zeros(3, dtype=torch.float32).pin_memory()
         self.use_fps = use_fps
         self.graph = None
         mv.draw_coins(dev)                       # allocates the device coin buffer (consumes 7 Python draws)
@@ -39,6 +39,9 @@ class GraphedDenoiseStep:
                 self._body()
         finally:
             mv.coins_preloaded = False
+        # the eager warm-up steps advanced the latents; capture itself executes nothing: start from the given ones
+        self.pano_lat.copy_(init_pano)
+        self.pers_lat.copy_(init_pers)
 
     def _body(self):
         inp = self.inp
@@ -57,6 +60,7 @@ class GraphedDenoiseStep:
                 relative_position_tensor=inp["relative_position_tensor"], pitchs_tensor=inp["pitchs_tensor"])
         finally:
             self.mv.coins_preloaded = was
+        self.pred_pano, self.pred_pers = pred_pano, pred_pers          # static graph-pool tensors (inspection / tests)
         new_pano = self.sch.fused_cfg_step(pred_pano[0:1], pred_pano[1:2], self.g, None, self.pano_lat, coef_dev=self.coef)
         new_pers = self.sch.fused_cfg_step(pred_pers[0:1], pred_pers[1:2], self.g, None, self.pers_lat, coef_dev=self.coef)
         self.pano_lat.copy_(new_pano)
@@ -64,10 +68,9 @@ class GraphedDenoiseStep:
 
     def _upload(self, t_host, draw=True):
         cx, cv = self.sch.coefficients(t_host)
-        self._t_host[0] = int(t_host)
-        self._coef_host[0], self._coef_host[1], self._coef_host[2] = self.g, cx, cv
-        self.timestep.copy_(self._t_host, non_blocking=True)
-        self.coef.copy_(self._coef_host, non_blocking=True)
+        # fresh pageable host tensors (staged at call time): safe when the host runs steps ahead of the GPU
+        self.timestep.copy_(torch.tensor([int(t_host)], dtype=torch.int64))
+        self.coef.copy_(torch.tensor([self.g, cx, cv], dtype=torch.float32))
         if draw:
             self.mv.draw_coins(self.timestep.device)
 

@@ -145,12 +145,10 @@ class MultiViewBaseModel(nn.Module):
         front keeps the stream identical.  They go to a small device tensor the attention kernels read."""
         if self._coins_dev is None or self._coins_dev.device != torch.device(device):
             self._coins_dev = torch.zeros(8, dtype=torch.int32, device=device)
-            self._coins_host = torch.zeros(8, dtype=torch.int32)
-            if torch.device(device).type == "cuda":
-                self._coins_host = self._coins_host.pin_memory()
-        for i in range(7):
-            self._coins_host[i] = 1 if random.random() < 0.4 else 0
-        self._coins_dev.copy_(self._coins_host, non_blocking=True)
+        # a fresh pageable host tensor per step: the runtime stages it at call time, so the host may run ahead of
+        # the GPU without a later step's coins overwriting an upload that has not executed yet
+        coins = torch.tensor([1 if random.random() < 0.4 else 0 for _ in range(7)] + [0], dtype=torch.int32)
+        self._coins_dev.copy_(coins)
         return self._coins_dev
 
     def _rig(self, cameras, m):
@@ -227,18 +225,29 @@ class MultiViewBaseModel(nn.Module):
             return a, e
 
         # ---- down (MVGenModel.py:261-326)
+        dbg = getattr(self, "debug_taps", None)
+        if dbg is not None:
+            dbg["conv_in"] = (x, px)
+            dbg["ctx"] = (ctx, pctx)
+            dbg["emb"] = (emb, pemb)
         skips, pskips = [x], [px]
         for i, (db, pdb) in enumerate(zip(un.down_blocks, pu.down_blocks)):
             for j in range(len(db.resnets)):
                 x = db.resnets[j].forward_cl(x, emb, f)
                 px = pdb.resnets[j].forward_cl(px, pemb, f, pano)
+                if dbg is not None:
+                    dbg[f"res{i}{j}"] = (x, px)
                 if db.has_cross_attention:           # DownBlock3D's motion modules are skipped (:292-303)
                     x = db.attentions[j].forward_cl(x, ctx, f)
+                    px = pdb.attentions[j].forward_cl(px, pctx, f)
+                    if dbg is not None:
+                        dbg[f"attn{i}{j}"] = (x, px)
                     if db.motion_modules[j] is not None:
                         x = db.motion_modules[j].forward_cl(x, f)
-                    px = pdb.attentions[j].forward_cl(px, pctx, f)
                     if pdb.motion_modules[j] is not None:
                         px = pdb.motion_modules[j].forward_cl(px, f)
+                    if dbg is not None:
+                        dbg[f"mm{i}{j}"] = (x, px)
                 skips.append(x)
                 pskips.append(px)
             if db.downsamplers is not None:
