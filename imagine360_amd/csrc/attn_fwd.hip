@@ -7,16 +7,23 @@
 //   cross-view WarpAttn attention src/modules/transformer.py:59-74 (d=32, additive bias shared by
 //                                 every (batch, head) -- mask[0] broadcast, transformer.py:68-70)
 //
-// Design (wave64, v_mfma_f32_32x32x16):
-//   * one wave owns 32 query rows; a workgroup of NW waves shares one (batch, head) and streams
-//     K/V in 64-key tiles through LDS (register prefetch of tile t+1 overlaps compute of tile t).
-//   * S^T = K Q^T ("swapped QK^T"): every lane holds 16 scores of ONE query column, so the row
-//     max/sum are in-lane reductions plus a single lane^32 exchange.
-//   * O^T += V^T P^T: the exponentiated scores are already in B-operand order; V is stored
-//     transposed in LDS ([D][64+4], pair-packed on the way in) and keys are consumed in the
-//     C-fragment's own order, so no cross-lane permutes are needed.  The running max / sum /
-//     rescale are lane-local because O^T keeps the query in the lane index.
+// Design (wave64, v_mfma_f32_32x32x16).  The loop is VALU-issue bound at d = 64 (PMC: ~16 VALU instructions per
+// MFMA before this layout), so everything below is about instructions per score, not about the matrix pipe:
+//   * one wave owns QB blocks of 32 query rows; a workgroup of NW waves shares one (batch, head) and streams K/V in
+//     64-key tiles through double-buffered LDS (register prefetch of tile t+2 overlaps compute of tile t, one
+//     barrier per tile).
+//   * S^T = K Q^T ("swapped QK^T"): every lane holds 16 scores of ONE query column, so the row max / sum are
+//     in-lane reductions plus a single lane^32 exchange, and P is already in MFMA B-operand order for O^T += V^T P^T.
+//   * Q is pre-multiplied by scale*log2(e) once (in registers) and the first QK^T MFMA of a chain takes a register
+//     block holding -running_max as its C operand: the MFMA result IS the exp2 argument -- no per-score fma.
+//   * the running max moves only when a tile exceeds it by more than RESCALE_THR (deferred rescale): the usual
+//     per-tile O / l rescale pass, and the refresh of the -max block, are rare events behind one uniform branch.
+//   * V is staged row-major (plain 16-byte LDS writes, no register transpose); the PV A-operand is gathered with
+//     gfx950's transposing LDS read (ds_read_b64_tr_b16), rows padded to 192 B (d = 64) so the 4 key rows one
+//     read touches fall into distinct bank windows.  All fragment reads are base-register + immediate offset.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace im360 {
 
@@ -36,21 +43,33 @@ constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between rescales
 
-template <typename T, int D, int NW, bool HAS_BIAS>
+// one ds_read_b64_tr_b16: within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
+// lanes (i >> 2), 4 + (i >> 2), 8 + (i >> 2), 12 + (i >> 2) -- i.e. column i of the 4 x 16 matrix whose row j is
+// formed by the chunks of lanes 4j .. 4j+3 (checked on hardware by tools/tr_probe.hip)
+template <typename T>
+__device__ __forceinline__ u32x2 lds_read_tr16(const T* lds_ptr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
+}
+
+template <typename T, int D, int NW, int QB, bool HAS_BIAS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
-    constexpr int VP = KVB;            // V^T tile pitch (elements): unpadded, 16-byte groups XOR-swizzled by row
+    constexpr int VP = D == 64 ? 96 : 32;   // V tile pitch: 192-B / 64-B rows -> rows r..r+3 hit 4 distinct 64-B bank windows
     constexpr int DC = D / 16;         // k-steps of the QK^T contraction
     constexpr int DV = D / 32;         // 32-wide blocks of the output head dim
-    constexpr int KCH = KVB * D / 8;   // 16-byte chunks in a K tile
-    constexpr int KLD = (KCH + NT - 1) / NT;
-    constexpr int VIT = (KVB / 2) * (D / 8);   // (key pair, 8-channel chunk) items of a V tile
-    constexpr int VLD = (VIT + NT - 1) / NT;
+    constexpr int CH = KVB * D / 8;    // 16-byte chunks in a K (or V) tile
+    constexpr int CLD = CH / NT;       // chunks per thread
+    constexpr int RSTEP = NT / (D / 8);     // tile rows between a thread's consecutive chunks
+    static_assert(CH % NT == 0 && NT % (D / 8) == 0, "staging pattern");
+    constexpr bool QK_ALL = QB == 1;             // both halves' scores up front (2 * 16 live score registers per block)
+    constexpr bool SHARE_K = QB == 1 || D < 64;  // one K fragment read feeds all query blocks
+    constexpr int KT = KVB * KP, VT = KVB * VP;  // tile sizes (elements)
 
-    // double-buffered K / V^T tiles: one barrier per KV tile (the next tile is written while this one is consumed)
-    __shared__ __attribute__((aligned(16))) T k_lds2[2][KVB * KP];
-    __shared__ __attribute__((aligned(16))) T vt_lds2[2][D * VP];
+    // double-buffered K / V tiles: one barrier per KV tile (the next tile is written while this one is consumed)
+    __shared__ __attribute__((aligned(16))) T k_lds2[2 * KT];
+    __shared__ __attribute__((aligned(16))) T v_lds2[2 * VT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -66,86 +85,229 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     const int bh = (int)(lb / p.nqt);
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = (int)(lb % p.nqt) * (32 * NW) + wid * 32;
+    const int q0 = (int)(lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
 
-    const T* qb = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
+    const T* qb_ = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
     const T* kb_ = (const T*)p.k + (long)(b / p.kv_group) * p.k_bs + (long)h * D;
     const T* vb = (const T*)p.v + (long)(b / p.kv_group) * p.v_bs + (long)h * D;
     const T* bias = (const T*)p.bias;
     if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) bias = (const T*)p.bias_alt;
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 dc + 8 hi .. +7]
-    int qrow = q0 + col;
-    const bool q_valid = qrow < p.Nq;
-    if (!q_valid) qrow = p.Nq - 1;
-    uint4 qf[DC];
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 dc + 8 hi .. +7] * scale * log2(e)
+    int qrow[QB];
+    bool q_valid[QB];
+    uint4 qf[QB][DC];
+    f32x16 o[QB][DV];
+    f32x16 negm[QB];                   // every register = -(running max), in scaled log2 units
+    float m_sc[QB], l_run[QB];
 #pragma unroll
-    for (int dc = 0; dc < DC; ++dc)
-        qf[dc] = *(const uint4*)(qb + (long)qrow * p.q_rs + dc * 16 + hi * 8);
-
-    f32x16 o[DV];
+    for (int qb = 0; qb < QB; ++qb) {
+        qrow[qb] = q0 + qb * 32 + col;
+        q_valid[qb] = qrow[qb] < p.Nq;
+        if (!q_valid[qb]) qrow[qb] = p.Nq - 1;
 #pragma unroll
-    for (int i = 0; i < DV; ++i)
+        for (int dc = 0; dc < DC; ++dc) {
+            float f[8];
+            unpack8<T>(*(const uint4*)(qb_ + (long)qrow[qb] * p.q_rs + dc * 16 + hi * 8), f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+            for (int j = 0; j < 8; ++j) f[j] *= p.scale_log2;
+            qf[qb][dc] = pack8<T>(f);
+        }
+#pragma unroll
+        for (int i = 0; i < DV; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][i][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
+        m_sc[qb] = 0.f;                // the first tile always moves it to that tile's max
+        l_run[qb] = 0.f;
+    }
 
     const int ntiles = (p.Nk + KVB - 1) / KVB;
-    uint4 kreg[KLD];
-    uint4 vreg[VLD][2];
+    const bool ragged = (p.Nk % KVB) != 0;      // the last tile is partial: clamp its rows, mask its scores
+    u32x4 kreg[CLD], vreg[CLD];
+
+    // per-thread staging slots: thread tid owns (row, 16-byte chunk) slots tid + i * NT of a tile (rows RSTEP apart),
+    // so one source pointer per operand advanced by a tile per load is all the address math
+    const int srow = tid / (D / 8), sc8 = tid % (D / 8);
+    const T* ksrc = kb_ + (long)srow * p.k_rs + sc8 * 8;
+    const T* vsrc = vb + (long)srow * p.v_rs + sc8 * 8;
+    const long k_tile = (long)KVB * p.k_rs, v_tile = (long)KVB * p.v_rs;
+    T* const kdst = k_lds2 + srow * KP + sc8 * 8;
+    T* const vdst = v_lds2 + srow * VP + sc8 * 8;
 
     auto load_tile = [&](int t) {
+        // a ragged last tile clamps its rows into range (always-executed loads: a predicated load inside an unrolled
+        // loop makes hipcc branch around it and drain vmcnt per load).  Out-of-range keys are masked to -inf in the
+        // tile body, so their (finite, duplicated) K/V rows never contribute.
+        const bool clamp = ragged && t == ntiles - 1;
         const int kv0 = t * KVB;
-#pragma unroll
-        for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * NT;
-            const int row = (c / (D / 8)) % KVB, c8 = c % (D / 8);
-            // unconditional loads (rows clamped into range): a predicated load inside an unrolled loop makes hipcc
-            // branch around it and drain vmcnt per load.  Out-of-range keys are masked to -inf below, so their
-            // (finite, duplicated) K/V rows never contribute.
-            const int rr = min(kv0 + row, p.Nk - 1);
-            kreg[i] = *(const uint4*)(kb_ + (long)rr * p.k_rs + (c8 % (D / 8)) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * NT;
-            const int kp = c / (D / 8), c8 = c % (D / 8);
-            const int r0 = min(kv0 + 2 * (kp % (KVB / 2)), p.Nk - 1), r1 = min(kv0 + 2 * (kp % (KVB / 2)) + 1, p.Nk - 1);
-            vreg[i][0] = *(const uint4*)(vb + (long)r0 * p.v_rs + c8 * 8);
-            vreg[i][1] = *(const uint4*)(vb + (long)r1 * p.v_rs + c8 * 8);
-        }
+        static_for<CLD>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T* ks = ksrc + (long)(i * RSTEP) * p.k_rs;
+            const T* vs = vsrc + (long)(i * RSTEP) * p.v_rs;
+            if (clamp) {
+                const long rr = min(kv0 + srow + i * RSTEP, p.Nk - 1);
+                ks = kb_ + rr * p.k_rs + sc8 * 8;
+                vs = vb + rr * p.v_rs + sc8 * 8;
+            }
+            kreg[i] = *(const u32x4*)ks;
+            vreg[i] = *(const u32x4*)vs;
+        });
+        ksrc += k_tile;
+        vsrc += v_tile;
     };
     auto store_tile = [&](int buf) {
-        T* k_lds = k_lds2[buf];
-        T* vt_lds = vt_lds2[buf];
+        static_for<CLD>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            *(u32x4*)(kdst + buf * KT + i * RSTEP * KP) = kreg[i];
+            *(u32x4*)(vdst + buf * VT + i * RSTEP * VP) = vreg[i];
+        });
+    };
+
+    // fragment read bases (per lane); everything else is an immediate offset
+    const int kfrag = col * KP + hi * 8;
+    const int l16 = lane & 15, half = (lane >> 4) & 1;
+    const int vfrag = (4 * hi + (l16 >> 2)) * VP + 16 * half + 4 * (l16 & 3);
+
+    // one 64-key tile against the wave's QB query blocks.  MASKED is only instantiated for a ragged last tile.
+    auto tile_body = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const T* kf = k_lds2 + (t & 1) * KT + kfrag;
+        const T* vf = v_lds2 + (t & 1) * VT + vfrag;
+        const int kv0 = t * KVB;
+
+        // bias words first (per tile at QB = 1, per half otherwise): their L2 latency hides under the QK^T MFMAs
+        uint2 bw[HAS_BIAS ? QB : 1][2][4];
+        auto load_bias = [&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            if (HAS_BIAS) {
 #pragma unroll
-        for (int i = 0; i < KLD; ++i) {
-            const int c = tid + i * NT;
-            const int row = c / (D / 8), c8 = c % (D / 8);
-            if (c < KCH) *(uint4*)(k_lds + row * KP + c8 * 8) = kreg[i];
-        }
+                for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int i = 0; i < VLD; ++i) {
-            const int c = tid + i * NT;
-            const int kp = c / (D / 8), c8 = c % (D / 8);
-            if (c < VIT) {
-                const uint32_t a[4] = {vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w};
-                const uint32_t bq[4] = {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w};
-                uint32_t* dst = (uint32_t*)vt_lds;
-                // position of key 2kp inside the row: within each 16-key chunk the 8 keys one lane-half consumes
-                // (C-fragment order) are made contiguous, so the PV operand is ONE 16-byte read
-                const int k0 = 2 * kp, kk = k0 & 15;
-                const int ps = (k0 & ~15) + (((kk >> 2) & 1) << 3) + (kk & 3) + ((kk >> 3) << 2);
+                    for (int g = 0; g < 4; ++g) {
+                        const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, p.Nk - 4);     // Nk % 4 == 0 (checked on the host)
+                        bw[qb][QK_ALL ? kb : 0][g] = *(const uint2*)(bias + (long)qrow[qb] * p.bias_rs + key0);
+                    }
+            }
+        };
+
+        // s[qb][kb][r] = log2-domain score minus the running max, for (query col of block qb, key kv0 + 32 kb + row(r, hi))
+        f32x16 s[QB][2];
+        // QK^T of half kb for query block qb (or all blocks sharing each K fragment read)
+        auto qk = [&](auto kbc, auto qbc, auto allc) {
+            constexpr int kb = decltype(kbc)::value, q1 = decltype(qbc)::value;
+            constexpr bool all = decltype(allc)::value;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // channels 2j (low halves) and 2j+1 (high halves) of keys 2kp, 2kp+1
-                    const uint32_t lo = (a[j] & 0xffffu) | (bq[j] << 16);
-                    const uint32_t hi_ = (a[j] >> 16) | (bq[j] & 0xffff0000u);
-                    const int r0 = c8 * 8 + 2 * j, r1 = r0 + 1;
-                    dst[(r0 * VP + ((((ps >> 3) ^ ((r0 >> 3) ^ r0)) & 7) << 3) + (ps & 7)) >> 1] = lo;
-                    dst[(r1 * VP + ((((ps >> 3) ^ ((r1 >> 3) ^ r1)) & 7) << 3) + (ps & 7)) >> 1] = hi_;
+            for (int dc = 0; dc < DC; ++dc) {
+                const uint4 a = *(const uint4*)(kf + kb * 32 * KP + dc * 16);
+#pragma unroll
+                for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
+                    s[qb][kb] = Elem<T>::mfma32(a, qf[qb][dc], dc == 0 ? negm[qb] : s[qb][kb]);
+            }
+        };
+        // online-softmax update of block qb over the halves [K0, K1), then O^T += V^T P^T for them
+        auto softmax_pv = [&](auto qbc, auto k0c, auto k1c) {
+            constexpr int qb = decltype(qbc)::value, K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+#pragma unroll
+            for (int kb = K0; kb < K1; ++kb) {
+                f32x16& sv = s[qb][kb];
+                if (HAS_BIAS) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint2 w = bw[qb][QK_ALL ? kb : 0][g];
+                        sv[4 * g + 0] = fmaf(unpack_lo<T>(w.x), LOG2E, sv[4 * g + 0]);
+                        sv[4 * g + 1] = fmaf(unpack_hi<T>(w.x), LOG2E, sv[4 * g + 1]);
+                        sv[4 * g + 2] = fmaf(unpack_lo<T>(w.y), LOG2E, sv[4 * g + 2]);
+                        sv[4 * g + 3] = fmaf(unpack_hi<T>(w.y), LOG2E, sv[4 * g + 3]);
+                    }
+                }
+                if (MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + mfma32_row(r, hi) >= p.Nk) sv[r] = -INFINITY;
                 }
             }
+            float mloc = s[qb][K0][0];
+#pragma unroll
+            for (int kb = K0; kb < K1; ++kb)
+#pragma unroll
+                for (int r = (kb == K0 ? 1 : 0); r < 16; ++r) mloc = fmaxf(mloc, s[qb][kb][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            // deferred rescale: the running max only moves when these keys exceed it by more than RESCALE_THR (log2
+            // units; P stays <= 2^THR), so the O / l rescale and the refresh of the -max block are rare.  The very
+            // first keys always set it.
+            const bool first = (t == 0) && (K0 == 0);
+            if (first || __any(mloc > RESCALE_THR)) {
+                const float delta = first ? mloc : fmaxf(mloc, 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_sc[qb] += delta;
+                l_run[qb] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DV; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qb][r] = -m_sc[qb];
+#pragma unroll
+                for (int kb = K0; kb < 2; ++kb)        // includes a later half whose QK^T already used the old max
+                    if (kb < K1 || QK_ALL)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[qb][kb][r] -= delta;
+            }
+#pragma unroll
+            for (int kb = K0; kb < K1; ++kb) {
+                // P = exp2(score - max), packed straight into MFMA B-operand order
+                float pv[16];
+                float lsum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+                    lsum += pv[r];
+                }
+                l_run[qb] += lsum;
+                const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
+                // O^T += V^T P^T: MFMA c covers the 16 keys 16c + {0..3, 8..11} + 4 hi (the C-fragment's own key
+                // order), gathered by two transposing reads; the two 32-channel accumulators alternate
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int dvb = 0; dvb < DV; ++dvb) {
+                        const T* src = vf + (kb * 32 + 16 * c) * VP + dvb * 32;
+                        const u32x2 w0 = lds_read_tr16(src), w1 = lds_read_tr16(src + 8 * VP);
+                        uint4 a;
+                        a.x = w0.x; a.y = w0.y; a.z = w1.x; a.w = w1.y;
+                        o[qb][dvb] = Elem<T>::mfma32(a, pf[c], o[qb][dvb]);
+                    }
+                }
+            }
+        };
+
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if constexpr (QK_ALL) {
+            load_bias(I0{});
+            load_bias(I1{});
+            // QB == 1: both halves' scores first (the two accumulators alternate), one max / rescale decision per tile
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const uint4 a = *(const uint4*)(kf + kb * 32 * KP + dc * 16);
+                    s[0][kb] = Elem<T>::mfma32(a, qf[0][dc], dc == 0 ? negm[0] : s[0][kb]);
+                }
+            softmax_pv(I0{}, I0{}, I2{});
+        } else {
+            static_for<2>([&](auto kbc) {
+                constexpr int kb = decltype(kbc)::value;
+                load_bias(kbc);
+                if constexpr (SHARE_K) qk(kbc, I0{}, std::true_type{});
+                static_for<QB>([&](auto qbc) {
+                    if constexpr (!SHARE_K) qk(kbc, qbc, std::false_type{});
+                    softmax_pv(qbc, kbc, std::integral_constant<int, kb + 1>{});
+                });
+            });
         }
     };
 
@@ -156,107 +318,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         __syncthreads();                 // tile t is visible; every wave is done with tile t-1 (buffer (t+1)&1)
         if (t + 1 < ntiles) store_tile((t + 1) & 1);
         if (t + 2 < ntiles) load_tile(t + 2);      // in flight during the whole compute phase below
-        const T* k_lds = k_lds2[t & 1];
-        const T* vt_lds = vt_lds2[t & 1];
-        const int kv0 = t * KVB;
-
-        // ---- S^T = K Q^T : s[kb][r] = score(query col, key kv0 + 32 kb + row(r, hi))
-        f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int dc = 0; dc < DC; ++dc) {
-                const uint4 a = *(const uint4*)(k_lds + (kb * 32 + col) * KP + dc * 16 + hi * 8);
-                s[kb] = Elem<T>::mfma32(a, qf[dc], s[kb]);
-            }
-        }
-        // ---- two 32-key halves, each with its own online-softmax update.  Issue order matters more than
-        //      instruction count here: the second half's QK^T MFMAs (issued above) run in the matrix pipe while the
-        //      first half's softmax runs on the VALU, and the first half's PV MFMAs run under the second half's softmax.
-        const float sc = HAS_BIAS ? 1.0f : p.scale_log2;            // p = exp2(u * sc - m * sc)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (HAS_BIAS) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, p.Nk - 4);     // Nk % 4 == 0 (checked on the host)
-                    const uint2 w = *(const uint2*)(bias + (long)qrow * p.bias_rs + key0);
-                    s[kb][4 * g + 0] = fmaf(s[kb][4 * g + 0], p.scale_log2, unpack_lo<T>(w.x) * LOG2E);
-                    s[kb][4 * g + 1] = fmaf(s[kb][4 * g + 1], p.scale_log2, unpack_hi<T>(w.x) * LOG2E);
-                    s[kb][4 * g + 2] = fmaf(s[kb][4 * g + 2], p.scale_log2, unpack_lo<T>(w.y) * LOG2E);
-                    s[kb][4 * g + 3] = fmaf(s[kb][4 * g + 3], p.scale_log2, unpack_hi<T>(w.y) * LOG2E);
-                }
-            }
-            if (kv0 + kb * 32 + 32 > p.Nk) {                        // only a partial last half masks keys
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kv0 + kb * 32 + mfma32_row(r, hi) >= p.Nk) s[kb][r] = -INFINITY;
-            }
-            float mloc = s[kb][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            // deferred rescale: keep the old running max while this half's max exceeds it by less than
-            // RESCALE_THR (log2 units), so P <= 2^THR and the O / l rescale pass is skipped for most halves
-            if (__any(mloc * sc > m_run * sc + RESCALE_THR)) {
-                const float m_new = fmaxf(m_run, mloc);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DV; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            }
-            // P = exp2(u * sc - m * sc), packed straight into MFMA B-operand order
-            const float msc = m_run * sc;
-            float pv[16];
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kb][r], sc, -msc));
-                lsum += pv[r];
-            }
-            l_run += lsum;
-            const uint4 pf0 = pack8<T>(pv), pf1 = pack8<T>(pv + 8);
-            // O^T += V^T P^T for this half
-#pragma unroll
-            for (int dvb = 0; dvb < DV; ++dvb) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int row = dvb * 32 + col;
-                    const int g = kb * 4 + 2 * c + hi;                 // 16-byte group holding this lane-half's 8 keys
-                    const uint4 vf = *(const uint4*)(vt_lds + row * VP + (((g ^ ((row >> 3) ^ row)) & 7) << 3));
-                    o[dvb] = Elem<T>::mfma32(vf, c == 0 ? pf0 : pf1, o[dvb]);
-                }
-            }
-        }
+        if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
+        else tile_body(t, std::false_type{});
     }
 
     // ---- epilogue: normalise, optional accumulate, store 4 consecutive channels per (lane, group)
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = p.out_scale / l_tot;
-    if (q_valid) {
-        T* ob = (T*)p.out + (long)b * p.o_bs + (long)qrow * p.o_rs + (long)h * D;
 #pragma unroll
-        for (int dvb = 0; dvb < DV; ++dvb) {
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        const float inv = p.out_scale / l_tot;
+        if (q_valid[qb]) {
+            T* ob = (T*)p.out + (long)b * p.o_bs + (long)qrow[qb] * p.o_rs + (long)h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float f[4];
+            for (int dvb = 0; dvb < DV; ++dvb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = o[dvb][4 * g + j] * inv;
-                uint2* dst = (uint2*)(ob + dvb * 32 + 8 * g + 4 * hi);
-                if (p.accumulate) {
-                    const uint2 old = *dst;
-                    f[0] += unpack_lo<T>(old.x); f[1] += unpack_hi<T>(old.x);
-                    f[2] += unpack_lo<T>(old.y); f[3] += unpack_hi<T>(old.y);
+                for (int g = 0; g < 4; ++g) {
+                    float f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = o[qb][dvb][4 * g + j] * inv;
+                    uint2* dst = (uint2*)(ob + dvb * 32 + 8 * g + 4 * hi);
+                    if (p.accumulate) {
+                        const uint2 old = *dst;
+                        f[0] += unpack_lo<T>(old.x); f[1] += unpack_hi<T>(old.x);
+                        f[2] += unpack_lo<T>(old.y); f[3] += unpack_hi<T>(old.y);
+                    }
+                    uint2 w;
+                    w.x = pack2<T>(f[0], f[1]);
+                    w.y = pack2<T>(f[2], f[3]);
+                    *dst = w;
                 }
-                uint2 w;
-                w.x = pack2<T>(f[0], f[1]);
-                w.y = pack2<T>(f[2], f[3]);
-                *dst = w;
             }
         }
     }
@@ -265,16 +355,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
-    p.nqt = (p.Nq + 32 * nw - 1) / (32 * nw);
+    // two query blocks per wave once that still leaves every CU several workgroups
+    static const int qb_env = getenv("IM360_ATTN_QB") ? atoi(getenv("IM360_ATTN_QB")) : 0;   // tuning override
+    int qb = (D == 32 && nw == 4 && p.Nq >= 256 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 1024) ? 2 : 1;   // d = 64 spills at QB = 2
+    if (qb_env && nw == 4) qb = qb_env == 2 ? 2 : 1;
+    p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);
     const long nblk = (long)p.B * p.H * p.nqt;
     if (nblk > 0x7fffffffL) {
         im360_set_error("attn_fwd: %ld workgroups exceed the grid limit", nblk);
         return IM360_ERR_ARG;
     }
     dim3 grid((unsigned)nblk, 1, 1);
-    if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
-    else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, HAS_BIAS>), grid, dim3(128), 0, stream, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+    if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
+    else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
+    else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

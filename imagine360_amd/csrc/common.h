@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 kernels of imagine360_amd.  CDNA4 only (wave64, MFMA).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -11,6 +12,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 16-byte register chunk as a native vector: copies of HIP's struct uint4 lower to memcpy and keep staging arrays in scratch
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // ---- element type traits: T is __bf16 or _Float16 (16-bit storage, fp32 math) ---------------
 template <typename T> struct Elem;
@@ -59,6 +64,16 @@ template <typename T> __device__ __forceinline__ uint4 pack8(const float* f) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>), for bodies that need the index as
+// a constant expression (register arrays, immediate LDS offsets)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // The MFMA 32x32x16 C/D fragment: lane l, register r holds C[row][col] with
 //   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
