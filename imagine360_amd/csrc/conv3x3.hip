@@ -39,16 +39,23 @@ struct ConvParams {
 // 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
 __device__ uint4 g_zero_chunk[1];
 
-// WM x WN waves of 64 x 64 outputs each: (2, 2) = 128 pixels x 128 couts; (4, 1) = 256 pixels x 64 couts, used when
-// Cout leaves a half-empty last 128-tile (Cout = 320: 5 exact 64-tiles instead of 3 x 128 = 17 % padded MFMA work)
-template <typename T, int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
-    constexpr int BM = WM * 64, BN = WN * 64;
+// WM x WN waves, each owning TM x TN blocks of 32 pixels x 32 couts:
+//   (2, 2, 2, 2) = 128 pixels x 128 couts, 4 waves     -- small problems, odd Cout
+//   (4, 1, 2, 2) = 256 pixels x 64 couts, 4 waves      -- Cout that leaves a half-empty last 128-tile
+//   (4, 2, 2, 5) = 256 pixels x 320 couts, 8 waves     -- the UNet's Cout = 320 / 640 / 1280 at large pixel counts.
+// The 128-wide tiles move 1 byte of operands into LDS per 64 flops and saturate the CU's global->LDS path at ~30 % of
+// the MFMA peak (same throughput at 2 or 3 resident workgroups); the 256 x 320 tile halves the bytes per flop
+// (142 flop/B) and runs as one 8-wave workgroup per CU (144 KB of LDS for the two stages).
+template <typename T, int BK, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
     constexpr int ROWB = BK * 2;                // bytes per tile row
     constexpr int RPB = 256 / ROWB;             // tile rows per 256-byte LDS bank row
-    constexpr int LDA = (BM * CPR) / 256;       // LDS-DMA loads per thread per K-step: activations
-    constexpr int LDB = (BN * CPR) / 256;       //                                         weights
+    static_assert((BM * CPR) % NT == 0 && (BN * CPR) % NT == 0, "staging pattern");
+    constexpr int LDA = (BM * CPR) / NT;       // LDS-DMA loads per thread per K-step: activations
+    constexpr int LDB = (BN * CPR) / NT;       //                                         weights
     constexpr int KC = BK / 16;
     constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB;     // bytes of the operand tiles
     constexpr int STAGE = TILE_A + TILE_B;
@@ -76,12 +83,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const T* wg = (const T*)p.w;
     const T* zero = (const T*)g_zero_chunk;
 
-    // per-thread staging slots: chunk c = i * 256 + tid -> tile row c / CPR, LDS position c % CPR
+    // per-thread staging slots: chunk c = i * NT + tid -> tile row c / CPR, LDS position c % CPR
     int pn[LDA], py[LDA], pxx[LDA], pd8[LDA];
     bool pvalid[LDA];
 #pragma unroll
     for (int i = 0; i < LDA; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         const int row = c / CPR;
         pd8[i] = ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;          // data chunk (elements) stored at this position
         const long m = m0 + row;
@@ -93,11 +100,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         pn[i] = (int)(t / p.Hout);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TN][TM];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TM; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     int ainc[LDA];
 #pragma unroll
     for (int i = 0; i < LDB; ++i) {
-        const int c = tid + i * 256, row = c / CPR;
+        const int c = tid + i * NT, row = c / CPR;
         bptr[i] = wg + (long)(n0 + row) * p.ntaps * p.Cin + ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;
     }
     int tap_p = 0, kk_p = 0;
@@ -143,13 +150,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < LDA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
-                                             (__attribute__((address_space(3))) void*)(abase + i * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(abase + i * (NT * 16)), 16, 0, 0);
             aptr[i] += ainc[i];
         }
 #pragma unroll
         for (int i = 0; i < LDB; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[i],
-                                             (__attribute__((address_space(3))) void*)(bbase + i * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
             bptr[i] += BK;
         }
         if (++kk_p == ksteps_per_tap) {
@@ -159,15 +166,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     };
 
     // fragment byte offsets inside a tile: row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16)
-    int woff[2][KC], xoff[2][KC];
+    int woff[TN][KC], xoff[TM][KC];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int rw = wn * 64 + a * 32 + col, rx = wm * 64 + a * 32 + col;
+    for (int kc = 0; kc < KC; ++kc) {
+        const int d = kc * 2 + hi;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const int d = kc * 2 + hi;
+        for (int a = 0; a < TN; ++a) {
+            const int rw = wn * (TN * 32) + a * 32 + col;
             woff[a][kc] = rw * ROWB + ((d ^ ((rw / RPB) & (CPR - 1))) * 16);
-            xoff[a][kc] = rx * ROWB + ((d ^ ((rx / RPB) & (CPR - 1))) * 16);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int rx = wm * (TM * 32) + b * 32 + col;
+            xoff[b][kc] = rx * ROWB + ((d ^ ((rx / RPB) & (CPR - 1))) * 16);
         }
     }
 
@@ -179,16 +190,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         const char* bt = at + TILE_A;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            uint4 wf[2], xf[2];
+            uint4 wf[TN], xf[TM];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                wf[a] = *(const uint4*)(bt + woff[a][kc]);
-                xf[a] = *(const uint4*)(at + xoff[a][kc]);
-            }
+            for (int a = 0; a < TN; ++a) wf[a] = *(const uint4*)(bt + woff[a][kc]);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < TM; ++b) xf[b] = *(const uint4*)(at + xoff[b][kc]);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = Elem<T>::mfma32(wf[a], xf[b], acc[a][b]);
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = Elem<T>::mfma32(wf[a], xf[b], acc[a][b]);
         }
     }
 
@@ -199,16 +209,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     T* yg = (T*)p.y;
     const bool vec = (p.Cout & 3) == 0;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const long m = m0 + wm * 64 + b * 32 + col;
+    for (int b = 0; b < TM; ++b) {
+        const long m = m0 + wm * (TM * 32) + b * 32 + col;
         if (m >= p.M) continue;
         const long img = m / ((long)p.Hout * p.Wout);
         const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TN; ++a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = n0 + wn * 64 + a * 32 + 8 * g + 4 * hi;
+                const int co = n0 + wn * (TN * 32) + a * 32 + 8 * g + 4 * hi;
                 if (co >= p.Cout) continue;
                 float f[4];
 #pragma unroll
@@ -247,29 +257,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
 }
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int TM, int TN>
 static int launch_conv_t(ConvParams p, hipStream_t stream) {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
     if (p.nblocks > 0x7fffffffL) {
         im360_set_error("conv_fwd: problem too large");
         return IM360_ERR_ARG;
     }
-    if (p.Cin % 64 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN>), dim3((unsigned)p.nblocks), dim3(256), 0, stream, p);
+    static const int bk_env = getenv("IM360_CONV_BK") ? atoi(getenv("IM360_CONV_BK")) : 0;   // tuning override
+    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0;      // the 256 x 320 tile is BK = 64 only
+    if ((p.Cin % 64 == 0 && bk_env != 32) || !has_bk32) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+    } else if constexpr (has_bk32) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+    }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
 
 template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
+    static const int big_env = getenv("IM360_CONV_BIG") ? atoi(getenv("IM360_CONV_BIG")) : 1;   // tuning override
+    // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
+    if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512)
+        return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
     // a last 128-wide cout tile that is at most half full wastes MFMA work: use 256 x 64 tiles instead
     const int rem = p.Cout % 128;
-    if (rem != 0 && rem <= 64 && p.Cout > 64) return launch_conv_t<T, 4, 1>(p, stream);
-    return launch_conv_t<T, 2, 2>(p, stream);
+    if (rem != 0 && rem <= 64 && p.Cout > 64) return launch_conv_t<T, 4, 1, 2, 2>(p, stream);
+    return launch_conv_t<T, 2, 2, 2, 2>(p, stream);
 }
 
 // weights [Cout, Cin, kh, kw] (PyTorch) -> [CoutPad128][kh*kw][CinPad] zero padded, K contiguous

@@ -179,6 +179,24 @@ def test_conv_epilogue_temb_residual_and_1x1(dt):
     assert rel(out, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,wrap", [(128, 32, 32, 64, 320, False), (33, 32, 64, 128, 640, True)])
+def test_conv3x3_256x320_tiles(dt, N, H, W, Cin, Cout, wrap):
+    """Shapes large enough (>= 512 workgroups of 256 pixels x 320 couts) to take the 8-wave big-tile kernel, including
+    a ragged last pixel tile, the circular wrap, and the temb / residual epilogue."""
+    Fr = N // 11 if N % 11 == 0 else 1
+    x = q16(rnd(N, H, W, Cin, seed=40), dt)
+    w = q16(rnd(Cout, Cin, 3, 3, seed=41, scale=(9 * Cin) ** -0.5), dt)
+    b = q16(rnd(Cout, seed=42, scale=0.1), dt)
+    temb = q16(rnd(N // Fr, Cout, seed=43), dt)
+    res = q16(rnd(N, H, W, Cout, seed=44), dt)
+    ref = _conv_ref(x, w, b, wrap_pad=1, unpad=1) if wrap else _conv_ref(x, w, b)
+    ref = ref + temb.repeat_interleave(Fr, 0)[:, None, None, :] + res
+    out = K.conv2d(x.to(dt).cuda(), K.pack_conv_weight(w.to(dt).cuda()), Cout, bias=b.to(dt).cuda(), wrap=wrap,
+                   temb=temb.to(dt).cuda(), imgs_per_temb=Fr, res=res.to(dt).cuda())
+    assert rel(out, ref) < TOL[dt]
+
+
 def test_circular_pad_and_cfg_ddim():
     dt = torch.bfloat16
     x = q16(rnd(3, 5, 16, 8, seed=30), dt)
