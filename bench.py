@@ -171,7 +171,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prof_kinds = ["conv", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
+    prof_kinds = ["conv", "gemm", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
     graphed = None
     if not args.no_graph:
         # the step is ~3000 launches: capture it once (hipGraph) and replay, so the host is out of the loop

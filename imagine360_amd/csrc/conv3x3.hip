@@ -202,12 +202,74 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
         }
     }
 
-    // ---- epilogue: lane (pixel = col, hi) holds 4 consecutive couts per register group
+    // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
+    //      lane would write 8 bytes at a pixel-row stride (32 rows x 16 B per instruction).  Instead each wave
+    //      transposes its tile through LDS (free after the K loop), 32 pixels at a time: bias / temb are added in
+    //      registers, the 16-bit rows are written to LDS, then read back row-major so consecutive lanes store (and
+    //      fetch the residual from) consecutive 8-byte pieces of one output row -- whole 128-byte lines.
     const T* bias = (const T*)p.bias;
     const T* temb = (const T*)p.temb;
     const T* res = (const T*)p.res;
     T* yg = (T*)p.y;
-    const bool vec = (p.Cout & 3) == 0;
+    const int nw0 = n0 + wn * (TN * 32);          // first cout of this wave
+    if ((p.Cout & 3) == 0) {
+        constexpr int RPITCH = TN * 64 + 8;       // LDS row pitch (bytes): 8-byte pieces of consecutive pixels rotate over the banks
+        constexpr int PIECES = TN * 8;            // 8-byte pieces per 32-pixel-block row
+        static_assert(NT / 64 * 32 * RPITCH <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
+        __syncthreads();                          // every wave is done reading the operand tiles
+        char* wlds = lds + wid_s * (32 * RPITCH);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block
+            const long m = mb + col;
+            const long img = (m < p.M ? m : p.M - 1) / ((long)p.Hout * p.Wout);
+            const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = nw0 + a * 32 + 8 * g + 4 * hi;
+                    const bool in = co < p.Cout;
+                    float f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
+                    if (bias && in) {
+                        const uint2 w = *(const uint2*)(bias + co);
+                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
+                    }
+                    if (trow && in) {
+                        const uint2 w = *(const uint2*)(trow + co);
+                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(f[0], f[1]);
+                    o.y = pack2<T>(f[2], f[3]);
+                    *(uint2*)(wlds + col * RPITCH + (a * 32 + 8 * g + 4 * hi) * 2) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * PIECES + 63) / 64; ++it) {
+                const int f = it * 64 + lane;
+                const int row = f / PIECES, pc = f % PIECES;
+                const long mr = mb + row;
+                const int co = nw0 + pc * 4;
+                if (row < 32 && mr < p.M && co < p.Cout) {
+                    uint2 o = *(const uint2*)(wlds + row * RPITCH + pc * 8);
+                    if (res) {
+                        const uint2 w = *(const uint2*)(res + mr * p.Cout + co);
+                        o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
+                        o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
+                    }
+                    *(uint2*)(yg + mr * p.Cout + co) = o;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
+        }
+        return;
+    }
+    // Cout not a multiple of 4 (never in the UNet / VAE): scalar stores straight from the fragments
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const long m = m0 + wm * (TM * 32) + b * 32 + col;
@@ -218,38 +280,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
         for (int a = 0; a < TN; ++a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = n0 + wn * (TN * 32) + a * 32 + 8 * g + 4 * hi;
-                if (co >= p.Cout) continue;
-                float f[4];
+                const int co = nw0 + a * 32 + 8 * g + 4 * hi;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
-                if (vec) {
-                    if (bias) {
-                        const uint2 w = *(const uint2*)(bias + co);
-                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
-                    }
-                    if (trow) {
-                        const uint2 w = *(const uint2*)(trow + co);
-                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
-                    }
-                    if (res) {
-                        const uint2 w = *(const uint2*)(res + m * p.Cout + co);
-                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
-                    }
-                    uint2 o;
-                    o.x = pack2<T>(f[0], f[1]);
-                    o.y = pack2<T>(f[2], f[3]);
-                    *(uint2*)(yg + m * p.Cout + co) = o;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (co + j < p.Cout) {
-                            float vv = f[j];
-                            if (bias) vv += to_f32(bias[co + j]);
-                            if (trow) vv += to_f32(trow[co + j]);
-                            if (res) vv += to_f32(res[m * p.Cout + co + j]);
-                            yg[m * p.Cout + co + j] = from_f32<T>(vv);
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    if (co + j < p.Cout) {
+                        float vv = acc[a][b][4 * g + j];
+                        if (bias) vv += to_f32(bias[co + j]);
+                        if (trow) vv += to_f32(trow[co + j]);
+                        if (res) vv += to_f32(res[m * p.Cout + co + j]);
+                        yg[m * p.Cout + co + j] = from_f32<T>(vv);
                     }
                 }
             }
@@ -331,7 +370,8 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
     p.M = N * Hout * Wout;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(PROF_CONV, stream);
+    // token-major linears routed through the kernel (1x1 taps on a [M, 1, 1, K] view) are accounted separately
+    ProfScope prof(ntaps == 1 && Hin == 1 && Win == 1 ? PROF_GEMM : PROF_CONV, stream);
     if (dtype == 0) return launch_conv<__bf16>(p, s);
     if (dtype == 1) return launch_conv<_Float16>(p, s);
     im360_set_error("conv_fwd: dtype %d unsupported", dtype);

@@ -32,7 +32,7 @@ _SIGNATURES = {
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
-PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5}
+PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
 
 
 def exported_symbols():

@@ -98,6 +98,26 @@ def layer_norm(norm, x, pre=None, post=None, post_div=1):
     return kernels.layer_norm(x.contiguous(), norm.weight, norm.bias, norm.eps, pre=pre, post=post, post_div=post_div)
 
 
+def _gemm_kernel_pays(m, k, n):
+    """Shapes where the implicit-GEMM conv kernel (as a 1x1 conv with its fused bias / residual epilogue) is at least
+    as fast as hipBLASLt + a separate residual add: its 256 x 320 tiles need K % 64 == 0, N % 320 == 0 and enough
+    tiles to fill the chip a few times (measured with tools/bench_kernels.py linear)."""
+    return k % 64 == 0 and n % 320 == 0 and ((m + 255) // 256) * (n // 320) >= 1024
+
+
+def linear_residual(lin, x, res):
+    """``lin(x) + res``.  Large token counts: one launch of the MFMA implicit-GEMM kernel with bias and residual in
+    its epilogue (no separate elementwise pass over the activations); otherwise hipBLASLt plus an add."""
+    n, k = lin.weight.shape
+    m = x.numel() // k
+    if not (x.is_cuda and _gemm_kernel_pays(m, k, n)) or res.shape[-1] != n:
+        return F.linear(x, lin.weight, lin.bias) + res
+    cache = lin.__dict__.setdefault("_im360_derived", DerivedCache())
+    wp = cache.get("w1x1", (lin.weight,), lambda: kernels.pack_conv_weight(lin.weight.detach().reshape(n, k, 1, 1)))
+    y = kernels.conv2d(x.contiguous().reshape(m, 1, 1, k), wp, n, bias=lin.bias, res=res.contiguous().reshape(m, 1, 1, n))
+    return y.reshape(*x.shape[:-1], n)
+
+
 class GEGLU(nn.Module):
     """x -> a * gelu(gate), (a | gate) = proj(x)  (diffusers/models/activations.py:93-125)."""
 
@@ -117,8 +137,9 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x):
-        return self.net[2](self.net[0](x))
+    def forward(self, x, residual=None):
+        h = self.net[0](x)
+        return self.net[2](h) if residual is None else linear_residual(self.net[2], h, residual)
 
 
 class QKVAttention(nn.Module):
@@ -141,8 +162,9 @@ class QKVAttention(nn.Module):
         self._derived = DerivedCache()
         self._use_memory_efficient_attention_xformers = False
 
-    def out_proj(self, x):
-        return self.to_out[0](x) if isinstance(self.to_out, nn.ModuleList) else self.to_out(x)
+    def out_proj(self, x, residual=None):
+        lin = self.to_out[0] if isinstance(self.to_out, nn.ModuleList) else self.to_out
+        return lin(x) if residual is None else linear_residual(lin, x, residual)
 
     def fused_qkv_weight(self):
         ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight)

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from . import kernels
 from .layers import (DerivedCache, FeedForward, InflatedConv3d, InflatedGroupNorm, QKVAttention, from_cl, layer_norm,
+                     linear_residual,
                      to_cl)
 
 
@@ -147,9 +148,10 @@ class IPCrossAttention(QKVAttention):
             ip = ip[:, :, :self.image_cross_attention_dim]
         return self.to_k(text), self.to_v(text), self.to_k_ip(ip), self.to_v_ip(ip)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, frames=None):
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, frames=None, residual=None):
         """hidden_states [(b f), n, c]; encoder_hidden_states [(b f), 141, d] (reference form) or [b, 141, d]
-        with ``frames`` given (one context per video)."""
+        with ``frames`` given (one context per video).  ``residual`` is added to the result (fused into the output
+        projection)."""
         kv_group = 1
         if frames is not None and encoder_hidden_states.shape[0] * frames == hidden_states.shape[0]:
             kv_group = frames
@@ -159,7 +161,7 @@ class IPCrossAttention(QKVAttention):
         out = kernels.attention(q, kt, vt, self.heads, scale=ls, kv_group=kv_group)
         kernels.attention(q, ki, vi, self.heads, scale=ls, kv_group=kv_group, out=out, accumulate=True,
                           out_scale=self.scale)
-        return self.out_proj(out)
+        return self.out_proj(out, residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -182,9 +184,9 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states=None, frames=None, **_):
         y = hidden_states
-        y = self.attn1.out_proj(self.attn1.self_attention(layer_norm(self.norm1, y))) + y
-        y = self.attn2(layer_norm(self.norm2, y), encoder_hidden_states, frames=frames) + y
-        return self.ff(layer_norm(self.norm3, y)) + y
+        y = self.attn1.out_proj(self.attn1.self_attention(layer_norm(self.norm1, y)), residual=y)
+        y = self.attn2(layer_norm(self.norm2, y), encoder_hidden_states, frames=frames, residual=y)
+        return self.ff(layer_norm(self.norm3, y), residual=y)
 
 
 @dataclass
@@ -213,8 +215,7 @@ class Transformer3DModel(nn.Module):
         y = self.proj_in(y)
         for blk in self.transformer_blocks:
             y = blk(y, ctx, frames=frames)
-        y = self.proj_out(y)
-        return y.reshape(n, h, w, c) + x
+        return linear_residual(self.proj_out, y, x.reshape(n, h * w, c)).reshape(n, h, w, c)
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
         x, f = to_cl(hidden_states)
@@ -259,9 +260,10 @@ class VersatileAttention(QKVAttention):
             self._pe_key, self._pe_val = key, self.pos_encoder.pe[0, f0:f0 + frames].to(dtype).contiguous()
         return self._pe_val
 
-    def forward(self, tokens, batch, frames, pixels):
+    def forward(self, tokens, batch, frames, pixels, residual=None):
         """tokens [batch*frames*pixels, C] token-major, ALREADY normalised and with the frame PE added (the
-        block's fused LayerNorm does both); ``frames`` = frames held by this rank."""
+        block's fused LayerNorm does both); ``frames`` = frames held by this rank.  ``residual`` is added to the
+        result inside the output projection."""
         c = tokens.shape[-1]
         sh = self.frame_shard
         qkv = self.qkv(tokens)
@@ -273,7 +275,7 @@ class VersatileAttention(QKVAttention):
             pp = q.shape[2]
             a = kernels.temporal_attention(q.reshape(-1, 3 * c), batch, sh.total, pp, self.heads)
             a = sh.pixels_to_frames(a.reshape(batch, sh.total, pp, c), pixels).reshape(-1, c)
-        return self.out_proj(a)
+        return self.out_proj(a, residual)
 
 
 class TemporalTransformerBlock(nn.Module):
@@ -288,8 +290,8 @@ class TemporalTransformerBlock(nn.Module):
     def forward(self, y, batch, frames, pixels):
         for attn, norm in zip(self.attention_blocks, self.norms):
             n = layer_norm(norm, y, post=attn.frame_pe(frames, y.dtype), post_div=pixels)      # LN, then + PE[frame]
-            y = attn(n, batch, frames, pixels) + y
-        return self.ff(layer_norm(self.ff_norm, y)) + y
+            y = attn(n, batch, frames, pixels, residual=y)
+        return self.ff(layer_norm(self.ff_norm, y), residual=y)
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -310,8 +312,7 @@ class TemporalTransformer3DModel(nn.Module):
         y = self.proj_in(y)
         for blk in self.transformer_blocks:
             y = blk(y, n // frames, frames, h * w)
-        y = self.proj_out(y)
-        return y.reshape(n, h, w, c) + x
+        return linear_residual(self.proj_out, y, x.reshape(n * h * w, c)).reshape(n, h, w, c)
 
 
 class VanillaTemporalModule(nn.Module):

@@ -109,7 +109,8 @@ int im360_layernorm(const void* x, const void* gamma, const void* beta, const vo
 int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream);
 
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
- * 3 gn_stats, 4 gn_apply).  collect() synchronises on the recorded events. */
+ * 3 gn_stats, 4 gn_apply, 5 layernorm/geglu/elementwise, 6 conv kernel used as a token-major linear).
+ * collect() synchronises on the recorded events. */
 void im360_prof_enable(unsigned mask);
 int im360_prof_collect(int kind, double* total_ms, long* launches);
 

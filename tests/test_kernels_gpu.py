@@ -197,6 +197,24 @@ def test_conv3x3_256x320_tiles(dt, N, H, W, Cin, Cout, wrap):
     assert rel(out, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_linear_residual_through_gemm_kernel(dt):
+    """Token counts large enough for layers.linear_residual to take the implicit-GEMM kernel (bias + residual in the
+    epilogue) instead of hipBLASLt + add; both must agree with the fp32 reference."""
+    from imagine360_amd import layers
+    M, Kd, N = 262144, 320, 320
+    assert layers._gemm_kernel_pays(M, Kd, N) and not layers._gemm_kernel_pays(M // 2, Kd, N)
+    lin = torch.nn.Linear(Kd, N).to(dt).cuda()
+    g = torch.Generator().manual_seed(50)
+    x = torch.randn(4, M // 4, Kd, generator=g).to(dt).cuda()
+    res = torch.randn(4, M // 4, N, generator=g).to(dt).cuda()
+    ref = F.linear(x.float(), lin.weight.float(), lin.bias.float()) + res.float()
+    out = layers.linear_residual(lin, x, res)
+    assert out.shape == res.shape and rel(out.cpu(), ref.cpu()) < TOL[dt]
+    small = layers.linear_residual(lin, x[:1, :1000], res[:1, :1000])        # hipBLASLt + add path
+    assert rel(small.cpu(), ref[:1, :1000].cpu()) < TOL[dt]
+
+
 def test_circular_pad_and_cfg_ddim():
     dt = torch.bfloat16
     x = q16(rnd(3, 5, 16, 8, seed=30), dt)
