@@ -65,6 +65,20 @@ template <typename T> __device__ __forceinline__ uint4 pack8(const float* f) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
+// exact-GELU x * Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below 16-bit output rounding):
+// ~16 VALU instructions instead of libdevice erff's ~50, for epilogues where the activation is not hidden behind HBM
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = fmaf(-pl * t, e, 1.0f);                 // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;                   // x/2 * (1 + sign(x) erf(|x|/sqrt 2))
+}
+
 // compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>), for bodies that need the index as
 // a constant expression (register arrays, immediate LDS offsets)
 template <int N, typename F>

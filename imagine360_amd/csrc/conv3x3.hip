@@ -33,6 +33,7 @@ struct ConvParams {
     long M;             // N * Hout * Wout
     int tiles_n;        // ceil(Cout / 128)
     long nblocks;
+    int dbg;            // tuning experiments only (IM360_CONV_DBG): 1 = skip the epilogue, 2 = skip the K loop
 };
 
 
@@ -46,8 +47,8 @@ __device__ uint4 g_zero_chunk[1];
 // The 128-wide tiles move 1 byte of operands into LDS per 64 flops and saturate the CU's global->LDS path at ~30 % of
 // the MFMA peak (same throughput at 2 or 3 resident workgroups); the 256 x 320 tile halves the bytes per flop
 // (142 flop/B) and runs as one 8-wave workgroup per CU (144 KB of LDS for the two stages).
-template <typename T, int BK, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) {
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0>
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int ksteps_per_tap = p.Cin / BK;
-    const int nsteps = p.ntaps * ksteps_per_tap;
+    const int nsteps = (p.dbg & 2) ? 0 : p.ntaps * ksteps_per_tap;
 
     // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
     // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
@@ -212,12 +213,84 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
     const T* res = (const T*)p.res;
     T* yg = (T*)p.y;
     const int nw0 = n0 + wn * (TN * 32);          // first cout of this wave
-    if ((p.Cout & 3) == 0) {
-        constexpr int RPITCH = TN * 64 + 8;       // LDS row pitch (bytes): 8-byte pieces of consecutive pixels rotate over the banks
-        constexpr int PIECES = TN * 8;            // 8-byte pieces per 32-pixel-block row
-        static_assert(NT / 64 * 32 * RPITCH <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
+    if (p.dbg & 1) { if (acc[0][0][0] == 12345.f) ((T*)p.y)[0] = from_f32<T>(0.f); return; }
+    // LDS transpose of one 32-pixel block of this wave: rows of ROWB bytes (TN or TN/2 blocks of 32 couts), unpadded
+    // and 16-byte aligned; the 16-byte piece index is XORed with row bits and the two 8-byte halves of a piece are
+    // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
+    // different bank pairs (checked exhaustively for 320- and 128-byte rows).  The row-major side reads whole pieces.
+    auto piece_xor = [](int row, int rowb) { return rowb == 128 ? (row & 7) : ((row >> 1) & 3); };
+    if constexpr (EPI == 1) {
+        // GEGLU epilogue (token-major linear only): the packed weight rows alternate 32 value rows / 32 gate rows of the
+        // same output channels, so accumulators (2i, 2i+1) hold value and gate of one channel in the same lane and
+        // register: out = (value + b) * gelu(gate + b), half as many columns as the GEMM is wide.
+        static_assert(TN % 2 == 0, "value / gate blocks come in pairs");
+        constexpr int ROWB = (TN / 2) * 64;
+        constexpr int PIECES = ROWB / 16;
+        static_assert(ROWB == 128, "swizzle pattern");
+        const int I = p.Cout / 2;
+        const int ow0 = nw0 / 2;                  // first output channel of this wave
+        __syncthreads();
+        char* wlds = lds + wid_s * (32 * ROWB);
+        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const long mb = m0 + wm * (TM * 32) + b * 32;
+#pragma unroll
+            for (int i = 0; i < TN / 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows (bias index)
+                    float v[4], t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[2 * i][b][4 * g + j]; t[j] = acc[2 * i + 1][b][4 * g + j]; }
+                    if (bias) {
+                        const uint2 wv = *(const uint2*)(bias + rv), wg = *(const uint2*)(bias + rg);
+                        v[0] += unpack_lo<T>(wv.x); v[1] += unpack_hi<T>(wv.x); v[2] += unpack_lo<T>(wv.y); v[3] += unpack_hi<T>(wv.y);
+                        t[0] += unpack_lo<T>(wg.x); t[1] += unpack_hi<T>(wg.x); t[2] += unpack_lo<T>(wg.y); t[3] += unpack_hi<T>(wg.y);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the unfused path rounds the projection to 16 bits before the activation: keep that rounding
+                        const float vr = to_f32(from_f32<T>(v[j])), tr = to_f32(from_f32<T>(t[j]));
+                        v[j] = vr * gelu_erf_fast(tr);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(v[0], v[1]);
+                    o.y = pack2<T>(v[2], v[3]);
+                    *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * PIECES + 63) / 64; ++it) {
+                const int f = it * 64 + lane;
+                const int row = f / PIECES, pc = f % PIECES;
+                const long mr = mb + row;
+                const int co = ow0 + pc * 8;
+                if (row < 32 && mr < p.M && co < I) {
+                    uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
+                    if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
+                    *(uint4*)(yg + mr * I + co) = o;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    } else {
+    // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
+    //      lane would write 8 bytes at a pixel-row stride (32 rows x 16 B per instruction).  Instead each wave
+    //      transposes its tile through LDS (free after the K loop), 32 pixels at a time: bias / temb are added in
+    //      registers, the 16-bit rows are written to LDS, then read back row-major so consecutive lanes store (and
+    //      fetch the residual from) consecutive 16-byte pieces of one output row -- whole 128-byte lines.
+    if ((p.Cout & 7) == 0) {
+        constexpr int ROWB = TN * 64;
+        constexpr int PIECES = ROWB / 16;
+        static_assert(ROWB == 128 || ROWB == 320, "swizzle pattern");
+        static_assert(NT / 64 * 32 * ROWB <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
         __syncthreads();                          // every wave is done reading the operand tiles
-        char* wlds = lds + wid_s * (32 * RPITCH);
+        char* wlds = lds + wid_s * (32 * ROWB);
+        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block
@@ -244,7 +317,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
                     uint2 o;
                     o.x = pack2<T>(f[0], f[1]);
                     o.y = pack2<T>(f[2], f[3]);
-                    *(uint2*)(wlds + col * RPITCH + (a * 32 + 8 * g + 4 * hi) * 2) = o;
+                    *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -253,15 +326,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
                 const int f = it * 64 + lane;
                 const int row = f / PIECES, pc = f % PIECES;
                 const long mr = mb + row;
-                const int co = nw0 + pc * 4;
+                const int co = nw0 + pc * 8;
                 if (row < 32 && mr < p.M && co < p.Cout) {
-                    uint2 o = *(const uint2*)(wlds + row * RPITCH + pc * 8);
+                    uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
+                    if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
                     if (res) {
-                        const uint2 w = *(const uint2*)(res + mr * p.Cout + co);
+                        const uint4 w = *(const uint4*)(res + mr * p.Cout + co);
                         o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
                         o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
+                        o.z = pack2<T>(unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z));
+                        o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
                     }
-                    *(uint2*)(yg + mr * p.Cout + co) = o;
+                    *(uint4*)(yg + mr * p.Cout + co) = o;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -269,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
         }
         return;
     }
-    // Cout not a multiple of 4 (never in the UNet / VAE): scalar stores straight from the fragments
+    // Cout not a multiple of 8 (conv_out's 4 channels, odd test shapes): stores straight from the fragments
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const long m = m0 + wm * (TM * 32) + b * 32 + col;
@@ -294,9 +370,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvParams p) 
             }
         }
     }
+    }
 }
 
-template <typename T, int WM, int WN, int TM, int TN>
+template <typename T, int WM, int WN, int TM, int TN, int EPI = 0>
 static int launch_conv_t(ConvParams p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
     p.tiles_n = (p.Cout + BN - 1) / BN;
@@ -306,11 +383,13 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         return IM360_ERR_ARG;
     }
     static const int bk_env = getenv("IM360_CONV_BK") ? atoi(getenv("IM360_CONV_BK")) : 0;   // tuning override
-    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0;      // the 256 x 320 tile is BK = 64 only
+    static const int dbg_env = getenv("IM360_CONV_DBG") ? atoi(getenv("IM360_CONV_DBG")) : 0;
+    p.dbg = dbg_env;
+    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI == 0;      // the 8-wave tiles are BK = 64 only
     if ((p.Cin % 64 == 0 && bk_env != 32) || !has_bk32) {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
@@ -360,7 +439,8 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     IM360_CHECK_ARG(stride == 1 || stride == 2, "conv_fwd: stride must be 1 or 2");
     IM360_CHECK_ARG(!(up && stride != 1), "conv_fwd: upsample input requires stride 1");
     IM360_CHECK_ARG(!temb || imgs_per_temb > 0, "conv_fwd: imgs_per_temb must be positive");
-    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 8) == 0,
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)temb % 8) == 0,
                     "conv_fwd: misaligned pointer");
     ConvParams p;
     p.x = x; p.w = w_packed; p.bias = bias; p.temb = temb; p.res = res; p.y = y;
@@ -375,6 +455,28 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     if (dtype == 0) return launch_conv<__bf16>(p, s);
     if (dtype == 1) return launch_conv<_Float16>(p, s);
     im360_set_error("conv_fwd: dtype %d unsupported", dtype);
+    return IM360_ERR_UNSUPPORTED;
+}
+
+extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
+                                  int64_t M, int64_t K, int64_t I, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w_packed && y, "linear_geglu: null pointer");
+    IM360_CHECK_ARG(M > 0 && K > 0 && (K % 64) == 0, "linear_geglu: K=%ld must be a positive multiple of 64", (long)K);
+    IM360_CHECK_ARG(I > 0 && (I % 128) == 0, "linear_geglu: I=%ld must be a positive multiple of 128", (long)I);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ((uintptr_t)bias_packed % 8) == 0, "linear_geglu: misaligned pointer");
+    ConvParams p;
+    p.x = x; p.w = w_packed; p.bias = bias_packed; p.temb = nullptr; p.res = nullptr; p.y = y;
+    p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)(2 * I); p.ntaps = 1;
+    p.stride = 1; p.up = 0; p.wrap = 0; p.x_off = 0; p.y_off = 0; p.imgs_per_temb = 1;
+    p.M = M;
+    IM360_CHECK_ARG(M <= 0x7fffffffL, "linear_geglu: M too large");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, stream);
+    if (dtype == 0) return launch_conv_t<__bf16, 4, 2, 2, 4, 1>(p, s);
+    if (dtype == 1) return launch_conv_t<_Float16, 4, 2, 2, 4, 1>(p, s);
+    im360_set_error("linear_geglu: dtype %d unsupported", dtype);
     return IM360_ERR_UNSUPPORTED;
 }
 

@@ -28,6 +28,7 @@ _SIGNATURES = {
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR, _PTR]),
     "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
     "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
+    "im360_linear_geglu": (_INT, [_PTR] * 4 + [_I64] * 3 + [_INT, _PTR]),
     "im360_prof_enable": (None, [ctypes.c_uint]),
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
@@ -226,6 +227,32 @@ def geglu(h):
     rc = lib().im360_geglu(_p(h), _p(out), h.numel() // (2 * I), I, _dt(h), _stream())
     _check(rc, "im360_geglu")
     return out
+
+
+def pack_geglu(weight, bias):
+    """GEGLU projection ``weight`` [2I, K] / ``bias`` [2I] (value half, then gate half) -> operands of
+    ``linear_geglu``: 32-row blocks of the two halves interleaved (v0, g0, v1, g1, ...), the weight in the conv
+    kernel's packed [rows][1][K] layout."""
+    two_i, k = weight.shape
+    i = two_i // 2
+    assert i % 128 == 0 and k % 64 == 0, (i, k)
+    w = torch.stack([weight[:i].reshape(i // 32, 32, k), weight[i:].reshape(i // 32, 32, k)], dim=1).reshape(two_i, k, 1, 1)
+    b = None
+    if bias is not None:
+        b = torch.stack([bias[:i].reshape(i // 32, 32), bias[i:].reshape(i // 32, 32)], dim=1).reshape(two_i).contiguous()
+    return pack_conv_weight(w.contiguous()), b
+
+
+def linear_geglu(x, w_packed, bias_packed, inner):
+    """x [..., K] -> (x W_v^T + b_v) * gelu(x W_g^T + b_g) [..., inner] in one launch (operands from ``pack_geglu``)."""
+    _dev(x, w_packed, bias_packed)
+    assert x.is_contiguous() and w_packed.shape[2] == x.shape[-1] and w_packed.shape[0] >= 2 * inner
+    k = x.shape[-1]
+    m = x.numel() // k
+    y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
+    rc = lib().im360_linear_geglu(_p(x), _p(w_packed), _p(bias_packed), _p(y), m, k, inner, _dt(x), _stream())
+    _check(rc, "im360_linear_geglu")
+    return y
 
 
 # ------------------------------------------------------------------------------------------ misc

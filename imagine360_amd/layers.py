@@ -105,17 +105,33 @@ def _gemm_kernel_pays(m, k, n):
     return k % 64 == 0 and n % 320 == 0 and ((m + 255) // 256) * (n // 320) >= 1024
 
 
-def linear_residual(lin, x, res):
-    """``lin(x) + res``.  Large token counts: one launch of the MFMA implicit-GEMM kernel with bias and residual in
-    its epilogue (no separate elementwise pass over the activations); otherwise hipBLASLt plus an add."""
-    n, k = lin.weight.shape
+def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1"):
+    """``x @ weight.T + bias (+ res)``.  Large token counts: one launch of the MFMA implicit-GEMM kernel (as a 1x1
+    conv over a [M, 1, 1, K] view) with bias and residual in its epilogue -- no separate elementwise pass over the
+    activations; otherwise hipBLASLt (+ an add).  ``cache``: DerivedCache holding the packed weight."""
+    n, k = weight.shape
     m = x.numel() // k
-    if not (x.is_cuda and _gemm_kernel_pays(m, k, n)) or res.shape[-1] != n:
-        return F.linear(x, lin.weight, lin.bias) + res
-    cache = lin.__dict__.setdefault("_im360_derived", DerivedCache())
-    wp = cache.get("w1x1", (lin.weight,), lambda: kernels.pack_conv_weight(lin.weight.detach().reshape(n, k, 1, 1)))
-    y = kernels.conv2d(x.contiguous().reshape(m, 1, 1, k), wp, n, bias=lin.bias, res=res.contiguous().reshape(m, 1, 1, n))
+    if not (x.is_cuda and _gemm_kernel_pays(m, k, n)) or (res is not None and res.shape[-1] != n):
+        y = F.linear(x, weight, bias)
+        return y if res is None else y + res
+    wp = cache.get(key, (weight,), lambda: kernels.pack_conv_weight(weight.detach().reshape(n, k, 1, 1)))
+    r4 = None if res is None else res.contiguous().reshape(m, 1, 1, n)
+    y = kernels.conv2d(x.contiguous().reshape(m, 1, 1, k), wp, n, bias=bias, res=r4)
     return y.reshape(*x.shape[:-1], n)
+
+
+def _module_cache(mod):
+    return mod.__dict__.setdefault("_im360_derived", DerivedCache())
+
+
+def linear(lin, x):
+    """nn.Linear forward through ``gemm_linear``."""
+    return gemm_linear(lin.weight, lin.bias, x, cache=_module_cache(lin))
+
+
+def linear_residual(lin, x, res):
+    """``lin(x) + res`` through ``gemm_linear``."""
+    return gemm_linear(lin.weight, lin.bias, x, res=res, cache=_module_cache(lin))
 
 
 class GEGLU(nn.Module):
@@ -126,6 +142,17 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
+        two_i, k = self.proj.weight.shape
+        m = x.numel() // k
+        # large token counts: projection, bias and the gated activation in ONE launch of the MFMA GEMM kernel (the
+        # 2I-wide intermediate never goes to HBM); otherwise hipBLASLt + the elementwise kernel
+        # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 320 at >= 128k tokens, ties at K = 640)
+        if x.is_cuda and k % 64 == 0 and k <= 512 and two_i % 256 == 0 and m >= 131072:
+            cache = _module_cache(self)
+            ps = (self.proj.weight,) if self.proj.bias is None else (self.proj.weight, self.proj.bias)
+            wp, bp = cache.get("geglu", ps, lambda: kernels.pack_geglu(self.proj.weight.detach(),
+                                                                        None if self.proj.bias is None else self.proj.bias.detach()))
+            return kernels.linear_geglu(x.contiguous(), wp, bp, two_i // 2)
         return kernels.geglu(self.proj(x))
 
 
@@ -172,7 +199,7 @@ class QKVAttention(nn.Module):
 
     def qkv(self, x):
         """x [..., C] -> fused [..., 3*inner] (valid when to_q/k/v share their input)."""
-        return F.linear(x, self.fused_qkv_weight())
+        return gemm_linear(self.fused_qkv_weight(), None, x, cache=self._derived, key="qkv_packed")
 
     def self_attention(self, x, bias=None):
         """x [B, N, C] -> attention output before the out projection."""
@@ -183,6 +210,6 @@ class QKVAttention(nn.Module):
     def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None):
         if encoder_hidden_states is None:
             return self.out_proj(self.self_attention(hidden_states))
-        q = self.to_q(hidden_states)
+        q = linear(self.to_q, hidden_states)
         k, v = self.to_k(encoder_hidden_states), self.to_v(encoder_hidden_states)
         return self.out_proj(kernels.attention(q, k, v, self.heads))

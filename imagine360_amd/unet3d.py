@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import kernels
 from .layers import (DerivedCache, FeedForward, InflatedConv3d, InflatedGroupNorm, QKVAttention, from_cl, layer_norm,
-                     linear_residual,
+                     linear, linear_residual,
                      to_cl)
 
 
@@ -156,7 +156,7 @@ class IPCrossAttention(QKVAttention):
         if frames is not None and encoder_hidden_states.shape[0] * frames == hidden_states.shape[0]:
             kv_group = frames
         kt, vt, ki, vi = self.project_context(encoder_hidden_states)
-        q = self.to_q(hidden_states)
+        q = linear(self.to_q, hidden_states)
         ls = self.dim_head ** -0.5 if self._use_memory_efficient_attention_xformers else self.scale
         out = kernels.attention(q, kt, vt, self.heads, scale=ls, kv_group=kv_group)
         kernels.attention(q, ki, vi, self.heads, scale=ls, kv_group=kv_group, out=out, accumulate=True,
@@ -212,7 +212,7 @@ class Transformer3DModel(nn.Module):
         """x [N, H, W, C]; ctx [N / frames, n_ctx, d] (one context per video)."""
         n, h, w, c = x.shape
         y = self.norm.forward_cl(x).reshape(n, h * w, c)
-        y = self.proj_in(y)
+        y = linear(self.proj_in, y)
         for blk in self.transformer_blocks:
             y = blk(y, ctx, frames=frames)
         return linear_residual(self.proj_out, y, x.reshape(n, h * w, c)).reshape(n, h, w, c)
@@ -309,7 +309,7 @@ class TemporalTransformer3DModel(nn.Module):
     def forward_cl(self, x, frames):
         n, h, w, c = x.shape
         y = self.norm.forward_cl(x).reshape(n * h * w, c)
-        y = self.proj_in(y)
+        y = linear(self.proj_in, y)
         for blk in self.transformer_blocks:
             y = blk(y, n // frames, frames, h * w)
         return linear_residual(self.proj_out, y, x.reshape(n * h * w, c)).reshape(n, h, w, c)

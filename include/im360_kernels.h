@@ -108,6 +108,15 @@ int im360_layernorm(const void* x, const void* gamma, const void* beta, const vo
  * Replaces: GEGLU, diffusers/models/activations.py:93-125; src/modules/transformer.py:10-16. */
 int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream);
 
+/* GEGLU feed-forward input projection in one launch: y[m, j] = (x W_v^T + b_v)[m, j] * gelu((x W_g^T + b_g)[m, j]),
+ * x [M, K] token-major, y [M, I].  w_packed / bias_packed hold the 2I rows of the projection with 32-row blocks of
+ * the value half and the gate half interleaved (v0, g0, v1, g1, ...; see kernels.pack_geglu), the weight in
+ * im360_pack_conv_weight's [rows][1][K] layout.  K % 64 == 0, I % 128 == 0.  The projection is rounded to 16 bits
+ * before the activation, like the two-kernel path.
+ * Replaces: GEGLU.forward, diffusers/models/activations.py:93-125 (Linear + chunk + F.gelu + mul). */
+int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
+                       int64_t M, int64_t K, int64_t I, int dtype, void* stream);
+
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
  * 3 gn_stats, 4 gn_apply, 5 layernorm/geglu/elementwise, 6 conv kernel used as a token-major linear).
  * collect() synchronises on the recorded events. */

@@ -136,7 +136,15 @@ def geglu(h):
     return (a * F.gelu(g)).to(h.dtype)
 
 
-_NAMES = ["layer_norm", "geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
+def pack_geglu(weight, bias):
+    return weight, bias
+
+
+def linear_geglu(x, w, b, inner):
+    return geglu(F.linear(x, w, b))
+
+
+_NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
           "conv2d", "circular_pad_w", "cfg_ddim_update"]
 
 

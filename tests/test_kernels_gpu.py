@@ -215,6 +215,28 @@ def test_linear_residual_through_gemm_kernel(dt):
     assert rel(small.cpu(), ref[:1, :1000].cpu()) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_linear_geglu_fused(dt):
+    """GEGLU projection + activation in one GEMM launch (interleaved value / gate weight rows) vs Linear -> chunk ->
+    a * gelu(gate) in fp32, including a ragged last token tile; and the module-level switch in layers.GEGLU."""
+    from imagine360_amd import layers
+    M, Kd, I = 40000 + 77, 128, 256
+    g = torch.Generator().manual_seed(60)
+    x = q16(torch.randn(M, Kd, generator=g), dt)
+    w = q16(torch.randn(2 * I, Kd, generator=g) * Kd ** -0.5, dt)
+    b = q16(torch.randn(2 * I, generator=g) * 0.1, dt)
+    h = q16(F.linear(x, w, b), dt)                      # the two-kernel path rounds the projection to 16 bits
+    ref = h[:, :I] * F.gelu(h[:, I:])
+    wp, bp = K.pack_geglu(w.to(dt).cuda(), b.to(dt).cuda())
+    out = K.linear_geglu(x.to(dt).cuda(), wp, bp, I)
+    assert out.shape == (M, I) and rel(out.cpu(), ref) < TOL[dt]
+    mod = layers.GEGLU(320, 1280).to(dt).cuda()
+    xx = torch.randn(2, 131072, 320, generator=g).to(dt).cuda()
+    fused = mod(xx)                                     # 1024 x 10 tiles: fused path
+    unfused = K.geglu(mod.proj(xx))
+    assert fused.shape == unfused.shape and rel(fused.cpu(), unfused.cpu()) < TOL[dt]
+
+
 def test_circular_pad_and_cfg_ddim():
     dt = torch.bfloat16
     x = q16(rnd(3, 5, 16, 8, seed=30), dt)

@@ -116,13 +116,25 @@ def bench_linear(iters):
         print(f"linear {name:16s} M={M:6d} K={Kd:4d} N={N:5d}: torch {t1 * 1e3:7.3f} ms {fl / t1 / 1e12:6.0f} TF/s | im360 1x1 {t2 * 1e3:7.3f} ms {fl / t2 / 1e12:6.0f} TF/s")
 
 
+def bench_geglu_fused(iters):
+    """GEGLU feed-forward input: hipBLASLt projection + elementwise kernel vs the single fused GEMM launch."""
+    import torch.nn.functional as F
+    for name, M, C in [("pers L0", 655360, 320), ("pano L0", 262144, 320), ("pers L1", 163840, 640), ("pers L2", 40960, 1280)]:
+        x, w, b = rn(M, C), rn(8 * C, C) * C ** -0.5, rn(8 * C)
+        t1 = timeit(lambda: K.geglu(F.linear(x, w, b)), iters)
+        wp, bp = K.pack_geglu(w, b)
+        t2 = timeit(lambda: K.linear_geglu(x, wp, bp, 4 * C), iters)
+        fl = 2.0 * M * C * 8 * C
+        print(f"geglu_fused {name:8s} M={M:6d} C={C:4d}: torch+geglu {t1 * 1e3:7.3f} ms | fused {t2 * 1e3:7.3f} ms {fl / t2 / 1e12:6.0f} TF/s")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 10
     if "--iters" in sys.argv:
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
         args = [a for a in args if a != str(iters)]
-    which = args or ["attn", "conv", "temporal", "ln", "gn", "linear"]
+    which = args or ["attn", "conv", "temporal", "ln", "gn", "linear", "geglu_fused"]
     torch.set_grad_enabled(False)
     for w in which:
         globals()["bench_" + w](iters)
