@@ -43,15 +43,6 @@ constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between rescales
 
-// one ds_read_b64_tr_b16: within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
-// lanes (i >> 2), 4 + (i >> 2), 8 + (i >> 2), 12 + (i >> 2) -- i.e. column i of the 4 x 16 matrix whose row j is
-// formed by the chunks of lanes 4j .. 4j+3 (checked on hardware by tools/tr_probe.hip)
-template <typename T>
-__device__ __forceinline__ u32x2 lds_read_tr16(const T* lds_ptr) {
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
-}
-
 template <typename T, int D, int NW, int QB, bool HAS_BIAS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     constexpr int NT = NW * 64;

@@ -32,6 +32,38 @@ template <> struct Elem<_Float16> {
     }
 };
 
+// 16 x 16 MFMA tiles (fp32 accumulators, 4 per lane): lane l of the A / B operand holds row / column l & 15 and the
+// 8 (x32) or 4 (x16) consecutive k elements starting at 8 * (l >> 4) / 4 * (l >> 4); C/D lane l holds column l & 15,
+// rows 4 * (l >> 4) .. +3.
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Mfma16;
+template <> struct Mfma16<__bf16> {
+    static __device__ __forceinline__ f32x4 k32(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4v, a), __builtin_bit_cast(s16x4v, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<_Float16> {
+    static __device__ __forceinline__ f32x4 k32(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 k16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    }
+};
+
+// one ds_read_b64_tr_b16: within a 16-lane group, lane i receives element (i & 3) of the 8-byte chunks addressed by
+// lanes (i >> 2), 4 + (i >> 2), 8 + (i >> 2), 12 + (i >> 2) -- i.e. column i of the 4 x 16 matrix whose row j is
+// formed by the chunks of lanes 4j .. 4j+3 (checked on hardware by tools/tr_probe.hip)
+template <typename T>
+__device__ __forceinline__ u32x2 lds_read_tr16(const T* lds_ptr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 

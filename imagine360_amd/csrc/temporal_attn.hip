@@ -5,10 +5,15 @@
 // including the '(b f) d c -> (b d) f c' / back layout shuffles (motion_module.py:348, 427): the
 // kernel indexes the token-major activations [B, F, P, heads*d] with strides instead of moving them.
 //
-// HBM-bound (16x16 scores, AI ~ 8 flop/B): no MFMA.  One thread owns QPT query rows of one (batch, pixel,
-// head); the threads of a pixel read the same K/V rows, so those loads are L1
-// broadcasts and HBM sees q, k, v, o exactly once.  Adjacent lanes are adjacent heads of the same
-// token, so a wave's 16-byte loads cover whole contiguous token rows.
+// HBM-bound by its data (AI ~ 8 flop/B) -- but only if the arithmetic is cheap: a scalar-FMA version spends ~3300
+// VALU instructions per query row unpacking 16-bit K/V and runs VALU-bound at ~1.7 TB/s.  Up to 16 frames (the
+// shipped configuration) therefore run on 16x16 MFMA tiles: one workgroup stages the q|k|v rows of one pixel (all
+// frames) into LDS with coalesced 16-byte loads, each wave takes (pixel, head) pairs: S^T = K Q^T in
+// ceil(d/32) MFMAs, softmax on the 4 scores a lane holds (+2 cross-lane exchanges), O^T = V^T P^T in ceil(d/16)
+// MFMAs with V gathered by the transposing LDS read, results written over the head's Q slice in LDS and then
+// streamed out as whole token rows.  HBM sees q, k, v, o exactly once.  Longer sequences (frame-sharded 48-frame
+// runs) use the scalar kernel below.
+#include <stdlib.h>
 #include "common.h"
 
 namespace im360 {
@@ -109,6 +114,91 @@ __global__ __launch_bounds__(512) void temporal_attn_lds_kernel(TAttnParams p, i
     }
 }
 
+// ---- F <= 16: one workgroup (4 waves) = one (batch, pixel) x hpb heads
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TAttnParams p, int hpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* rows = (T*)smem;                                 // [16 frames][q_g | k_g | v_g | 8 pad], g = this block's heads
+    const int F = p.F, d = p.d;
+    const int G = hpb * d;
+    const int pitch = 3 * G + 8;                        // +16 bytes: the 16 frame rows start 4 banks apart
+    const int h0 = blockIdx.y * hpb;
+    const int tid = threadIdx.x;
+    const long pix = blockIdx.x;
+    const long b = pix / p.P, px = pix % p.P;
+    // ---- stage: chunk id -> (frame, q|k|v, 16-byte chunk); frames >= F are zero rows
+    const int cps = G >> 3;
+    for (int c = tid; c < 16 * 3 * cps; c += 256) {
+        const int ch = c % cps, seg = (c / cps) % 3, f = c / (3 * cps);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (f < F) {
+            const T* base = seg == 0 ? (const T*)p.q + b * p.q_bs + px * p.q_ps + (long)f * p.q_fs
+                          : seg == 1 ? (const T*)p.k + b * p.k_bs + px * p.k_ps + (long)f * p.k_fs
+                                     : (const T*)p.v + b * p.v_bs + px * p.v_ps + (long)f * p.v_fs;
+            v = *(const uint4*)(base + h0 * d + ch * 8);
+        }
+        *(uint4*)(rows + f * pitch + seg * G + ch * 8) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int nstep = (d + 31) >> 5, ncb = (d + 15) >> 4;
+    for (int hl = wid; hl < hpb; hl += 4) {
+        // ---- S^T = K Q^T: lane (query i16, g) ends up with the scores of keys 4g .. 4g+3
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nstep; ++st) {
+            const int k0 = st * 32 + 8 * g;
+            uint4 kf = make_uint4(0u, 0u, 0u, 0u), qf = kf;
+            if (k0 < d) {                                // d % 8 == 0: an 8-channel chunk is all in or all out
+                kf = *(const uint4*)(rows + i16 * pitch + G + hl * d + k0);
+                qf = *(const uint4*)(rows + i16 * pitch + hl * d + k0);
+            }
+            s = Mfma16<T>::k32(kf, qf, s);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = (4 * g + r < F) ? s[r] * p.scale_log2 : -INFINITY;
+            m = fmaxf(m, s[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m);
+            l += s[r];
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        u32x2 pf;                                        // P^T as the B operand: column = query, k = keys 4g .. 4g+3
+        pf.x = pack2<T>(s[0], s[1]);
+        pf.y = pack2<T>(s[2], s[3]);
+        // ---- O^T = V^T P^T per 16-channel block; lane (query i16, g) gets channels c0 + 4g .. +3
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int c0 = cb * 16;
+            const u32x2 vf = lds_read_tr16(rows + (4 * g + (i16 >> 2)) * pitch + 2 * G + hl * d + c0 + 4 * (i16 & 3));
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            o = Mfma16<T>::k16(vf, pf, o);
+            if (c0 + 4 * g < d) {                        // the head's Q slice is dead after QK^T: park the output there
+                uint2 w;
+                w.x = pack2<T>(o[0] * inv, o[1] * inv);
+                w.y = pack2<T>(o[2] * inv, o[3] * inv);
+                *(uint2*)(rows + i16 * pitch + hl * d + c0 + 4 * g) = w;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- whole token rows out
+    for (int c = tid; c < 16 * cps; c += 256) {
+        const int ch = c % cps, f = c / cps;
+        if (f < F)
+            *(uint4*)((T*)p.out + b * p.o_bs + px * p.o_ps + (long)f * p.o_fs + h0 * d + ch * 8) =
+                *(const uint4*)(rows + f * pitch + ch * 8);
+    }
+}
+
 template <typename T, int FMAX>
 static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
     const long npix = p.total / ((long)p.F * p.heads);                 // B * P
@@ -127,6 +217,19 @@ static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
 
 template <typename T>
 static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
+    static const int scalar_env = getenv("IM360_TATTN_SCALAR") ? atoi(getenv("IM360_TATTN_SCALAR")) : 0;   // tuning override
+    if (p.F <= 16 && !scalar_env) {
+        int hpb = p.heads;                               // heads per workgroup: ~32 KB of LDS rows (3 * hpb * d <= 1248 channels)
+        while (hpb > 1 && (hpb % 2) == 0 && hpb * p.d > 416) hpb /= 2;
+        const size_t lds = (size_t)16 * (3 * hpb * p.d + 8) * sizeof(T) + 64;
+        if (lds <= 64 * 1024) {
+            const long npix = p.total / ((long)p.F * p.heads);
+            dim3 grid((unsigned)npix, (unsigned)(p.heads / hpb));
+            hipLaunchKernelGGL((temporal_attn_mfma_kernel<T>), grid, dim3(256), lds, stream, p, hpb);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
     if (p.F <= 16) launch_tattn_v<T, 16>(p, stream);
     else if (p.F <= 32) launch_tattn_v<T, 32>(p, stream);
     else launch_tattn_v<T, 64>(p, stream);
