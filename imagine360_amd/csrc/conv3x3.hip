@@ -84,21 +84,22 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
     const T* wg = (const T*)p.w;
     const T* zero = (const T*)g_zero_chunk;
 
-    // per-thread staging slots: chunk c = i * NT + tid -> tile row c / CPR, LDS position c % CPR
-    int pn[LDA], py[LDA], pxx[LDA], pd8[LDA];
-    bool pvalid[LDA];
+    // per-thread staging slots: chunk c = i * NT + tid -> tile row c / CPR = tid / CPR + i * (NT / CPR), LDS position
+    // c % CPR = tid % CPR.  NT / CPR is a multiple of 32, so the swizzled data chunk is the same for every i; the pixel
+    // coordinates are kept packed (y | x << 16, n | valid << 31) to leave registers for the MFMA operands.
+    constexpr int RPI = NT / CPR;               // tile rows between a thread's consecutive chunks
+    static_assert(RPI % 32 == 0, "staging rows");
+    const int srow = tid / CPR;
+    const int pd8 = ((tid % CPR) ^ ((srow / RPB) & (CPR - 1))) * 8;        // data chunk (elements) stored at this position
+    uint32_t pyx[LDA], pnv[LDA];
 #pragma unroll
     for (int i = 0; i < LDA; ++i) {
-        const int c = tid + i * NT;
-        const int row = c / CPR;
-        pd8[i] = ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;          // data chunk (elements) stored at this position
-        const long m = m0 + row;
-        pvalid[i] = m < p.M;
-        const long mm = pvalid[i] ? m : 0;
-        pxx[i] = (int)(mm % p.Wout);
+        const long m = m0 + srow + i * RPI;
+        const bool valid = m < p.M;
+        const long mm = valid ? m : 0;
         const long t = mm / p.Wout;
-        py[i] = (int)(t % p.Hout);
-        pn[i] = (int)(t / p.Hout);
+        pyx[i] = (uint32_t)(t % p.Hout) | ((uint32_t)(mm % p.Wout) << 16);
+        pnv[i] = (uint32_t)(t / p.Hout) | (valid ? 0x80000000u : 0u);
     }
 
     f32x16 acc[TN][TM];
@@ -116,30 +117,27 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
     // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
     // steps; the packed weights [cout][tap][cin] are contiguous across taps, so their pointers just keep advancing.
     const T* aptr[LDA];
-    const T* bptr[LDB];
-    int ainc[LDA];
-#pragma unroll
-    for (int i = 0; i < LDB; ++i) {
-        const int c = tid + i * NT, row = c / CPR;
-        bptr[i] = wg + (long)(n0 + row) * p.ntaps * p.Cin + ((c % CPR) ^ ((row / RPB) & (CPR - 1))) * 8;
-    }
+    uint32_t amask = 0;                         // bit i: slot i reads real pixels (advances with K), else the zero chunk
+    // weights: the thread's LDB rows are RPI rows apart -> one pointer + a uniform stride
+    const T* bptr = wg + (long)(n0 + srow) * p.ntaps * p.Cin + pd8;
+    const long bstride = (long)RPI * p.ntaps * p.Cin;
     int tap_p = 0, kk_p = 0;
     auto set_tap = [&](int tap) {
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
 #pragma unroll
         for (int i = 0; i < LDA; ++i) {
-            int gy = py[i] * p.stride + dy - 1 + p.y_off;
-            int gx = pxx[i] * p.stride + dx - 1 + p.x_off;
-            bool ok = pvalid[i] && gy >= 0 && gy < Hc;
+            int gy = (int)(pyx[i] & 0xffffu) * p.stride + dy - 1 + p.y_off;
+            int gx = (int)(pyx[i] >> 16) * p.stride + dx - 1 + p.x_off;
+            bool ok = (pnv[i] >> 31) && gy >= 0 && gy < Hc;
             if (p.wrap) {
                 gx = gx < 0 ? gx + Wc : (gx >= Wc ? gx - Wc : gx);      // |shift| <= 2 < Wc: one conditional wrap
             } else {
                 ok = ok && gx >= 0 && gx < Wc;
             }
             const int sy = gy >> p.up, sx = gx >> p.up;
-            const long off = ok ? (((long)pn[i] * p.Hin + sy) * p.Win + sx) * p.Cin + pd8[i] : 0;
+            const long off = ok ? (((long)(pnv[i] & 0x7fffffffu) * p.Hin + sy) * p.Win + sx) * p.Cin + pd8 : 0;
             aptr[i] = ok ? xg + off : zero;
-            ainc[i] = ok ? BK : 0;
+            amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
         }
     };
     set_tap(0);
@@ -152,36 +150,28 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
         for (int i = 0; i < LDA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
                                              (__attribute__((address_space(3))) void*)(abase + i * (NT * 16)), 16, 0, 0);
-            aptr[i] += ainc[i];
+            aptr[i] += ((amask >> i) & 1u) ? BK : 0;
         }
 #pragma unroll
         for (int i = 0; i < LDB; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)bptr[i],
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr + i * bstride),
                                              (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
-            bptr[i] += BK;
         }
+        bptr += BK;
         if (++kk_p == ksteps_per_tap) {
             kk_p = 0;
             if (++tap_p < p.ntaps) set_tap(tap_p);
         }
     };
 
-    // fragment byte offsets inside a tile: row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16)
-    int woff[TN][KC], xoff[TM][KC];
+    // fragment byte offsets inside a tile: row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16).  Every row a lane reads
+    // is its base row + a multiple of 32, and swz only looks at row bits below 32, so the swizzled chunk offset is one
+    // register per K chunk (shared by both operands) and the 32-row blocks are immediate offsets.
+    const int swz = (col / RPB) & (CPR - 1);
+    int koff[KC];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        const int d = kc * 2 + hi;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int rw = wn * (TN * 32) + a * 32 + col;
-            woff[a][kc] = rw * ROWB + ((d ^ ((rw / RPB) & (CPR - 1))) * 16);
-        }
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const int rx = wm * (TM * 32) + b * 32 + col;
-            xoff[b][kc] = rx * ROWB + ((d ^ ((rx / RPB) & (CPR - 1))) * 16);
-        }
-    }
+    for (int kc = 0; kc < KC; ++kc) koff[kc] = ((kc * 2 + hi) ^ swz) * 16;
+    const int wrow = (wn * (TN * 32) + col) * ROWB, xrow = (wm * (TM * 32) + col) * ROWB;
 
     stage(0);
     for (int s = 0; s < nsteps; ++s) {
@@ -189,18 +179,33 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
         if (s + 1 < nsteps) stage((s + 1) & 1);
         const char* at = lds + (s & 1) * STAGE;
         const char* bt = at + TILE_A;
+        // software-pipelined fragment reads: the pixel fragments and the first TN - LATE weight fragments of K chunk
+        // kc+1 are fetched while the MFMAs of chunk kc run (two register sets); the last LATE weight fragments of a
+        // chunk are fetched at its start and consumed by its last MFMAs -- the most prefetch 256 registers allow
+        constexpr int LATE = TN >= 4 ? 2 : 0;
+        u32x4 wf[2][TN - LATE], xf[2][TM], wl[LATE ? LATE : 1];
+        auto fetch = [&](auto kcc) {
+            constexpr int kc = decltype(kcc)::value;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            uint4 wf[TN], xf[TM];
+            for (int b = 0; b < TM; ++b) xf[kc & 1][b] = *(const u32x4*)(at + xrow + koff[kc] + b * (32 * ROWB));
 #pragma unroll
-            for (int a = 0; a < TN; ++a) wf[a] = *(const uint4*)(bt + woff[a][kc]);
+            for (int a = 0; a < TN - LATE; ++a) wf[kc & 1][a] = *(const u32x4*)(bt + wrow + koff[kc] + a * (32 * ROWB));
+        };
+        fetch(std::integral_constant<int, 0>{});
+        static_for<KC>([&](auto kcc) {
+            constexpr int kc = decltype(kcc)::value;
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xf[b] = *(const uint4*)(at + xoff[b][kc]);
+            for (int a = 0; a < LATE; ++a) wl[a] = *(const u32x4*)(bt + wrow + koff[kc] + (TN - LATE + a) * (32 * ROWB));
+            if constexpr (kc + 1 < KC) fetch(std::integral_constant<int, kc + 1>{});
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this chunk's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = Elem<T>::mfma32(wf[a], xf[b], acc[a][b]);
-        }
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, a < TN - LATE ? wf[kc & 1][a < TN - LATE ? a : 0] : wl[a >= TN - LATE ? a - (TN - LATE) : 0]),
+                                                __builtin_bit_cast(uint4, xf[kc & 1][b]), acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 
     // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
@@ -439,6 +444,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     IM360_CHECK_ARG(stride == 1 || stride == 2, "conv_fwd: stride must be 1 or 2");
     IM360_CHECK_ARG(!(up && stride != 1), "conv_fwd: upsample input requires stride 1");
     IM360_CHECK_ARG(!temb || imgs_per_temb > 0, "conv_fwd: imgs_per_temb must be positive");
+    IM360_CHECK_ARG(Hout <= 0xffff && Wout <= 0xffff && N <= 0x7fffffffL, "conv_fwd: Hout, Wout must fit 16 bits");
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                     ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)temb % 8) == 0,
                     "conv_fwd: misaligned pointer");

@@ -146,8 +146,8 @@ class GEGLU(nn.Module):
         m = x.numel() // k
         # large token counts: projection, bias and the gated activation in ONE launch of the MFMA GEMM kernel (the
         # 2I-wide intermediate never goes to HBM); otherwise hipBLASLt + the elementwise kernel
-        # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 320 at >= 128k tokens, ties at K = 640)
-        if x.is_cuda and k % 64 == 0 and k <= 512 and two_i % 256 == 0 and m >= 131072:
+        # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 640 at >= 128k tokens, loses at K = 1280 / 40k)
+        if x.is_cuda and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= 131072:
             cache = _module_cache(self)
             ps = (self.proj.weight,) if self.proj.bias is None else (self.proj.weight, self.proj.bias)
             wp, bp = cache.get("geglu", ps, lambda: kernels.pack_geglu(self.proj.weight.detach(),
