@@ -302,6 +302,22 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
             const long m = mb + col;
             const long img = (m < p.M ? m : p.M - 1) / ((long)p.Hout * p.Wout);
             const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
+            // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
+            // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
+            constexpr int NIT = (32 * PIECES + 63) / 64, NIT1 = NIT / 2;
+            u32x4 rv[NIT];
+            auto load_res = [&](int it0, int it1) {
+#pragma unroll
+                for (int it = it0; it < it1; ++it) {
+                    const int f = it * 64 + lane;
+                    const int row = f / PIECES, pc = f % PIECES;
+                    const long mr = mb + row;
+                    const int co = nw0 + pc * 8;
+                    rv[it] = u32x4{0u, 0u, 0u, 0u};
+                    if (res && row < 32 && mr < p.M && co < p.Cout) rv[it] = *(const u32x4*)(res + mr * p.Cout + co);
+                }
+            };
+            load_res(0, NIT1);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -324,10 +340,11 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
                     o.y = pack2<T>(f[2], f[3]);
                     *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                 }
+            load_res(NIT1, NIT);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < (32 * PIECES + 63) / 64; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 const int f = it * 64 + lane;
                 const int row = f / PIECES, pc = f % PIECES;
                 const long mr = mb + row;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
                     uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
                     if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
                     if (res) {
-                        const uint4 w = *(const uint4*)(res + mr * p.Cout + co);
+                        const u32x4 w = rv[it];
                         o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
                         o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
                         o.z = pack2<T>(unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z));
