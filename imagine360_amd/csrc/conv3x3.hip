@@ -44,6 +44,8 @@ __device__ uint4 g_zero_chunk[1];
 //   (2, 2, 2, 2) = 128 pixels x 128 couts, 4 waves     -- small problems, odd Cout
 //   (4, 1, 2, 2) = 256 pixels x 64 couts, 4 waves      -- Cout that leaves a half-empty last 128-tile
 //   (4, 2, 2, 5) = 256 pixels x 320 couts, 8 waves     -- the UNet's Cout = 320 / 640 / 1280 at large pixel counts.
+// EPI: 0 = conv epilogue (bias, temb, residual); 1 = GEGLU; 2 = same as 0, instantiated under its own symbol for the
+// token-major Linear use so that profiles tell the two apart.
 // The 128-wide tiles move 1 byte of operands into LDS per 64 flops and saturate the CU's global->LDS path at ~30 % of
 // the MFMA peak (same throughput at 2 or 3 resident workgroups); the 256 x 320 tile halves the bytes per flop
 // (142 flop/B) and runs as one 8-wave workgroup per CU (144 KB of LDS for the two stages).
@@ -421,8 +423,10 @@ template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     static const int big_env = getenv("IM360_CONV_BIG") ? atoi(getenv("IM360_CONV_BIG")) : 1;   // tuning override
     // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
-    if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512)
+    if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
+        if (p.ntaps == 1 && p.Hin == 1 && p.Win == 1) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
         return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
+    }
     // a last 128-wide cout tile that is at most half full wastes MFMA work: use 256 x 64 tiles instead
     const int rem = p.Cout % 128;
     if (rem != 0 && rem <= 64 && p.Cout > 64) return launch_conv_t<T, 4, 1, 2, 2>(p, stream);
