@@ -229,18 +229,27 @@ def geglu(h):
     return out
 
 
+def interleave_geglu(weight, bias):
+    """Row order of the fused GEGLU GEMM: 32-row blocks of the value half and the gate half alternate, so packed rows
+    [64 q, 64 q + 32) are value rows [32 q, 32 q + 32) and packed rows [64 q + 32, 64 q + 64) the matching gate rows."""
+    two_i = weight.shape[0]
+    i = two_i // 2
+    assert i % 32 == 0
+    w = torch.stack([weight[:i].reshape(i // 32, 32, -1), weight[i:].reshape(i // 32, 32, -1)], dim=1).reshape(two_i, -1)
+    b = None
+    if bias is not None:
+        b = torch.stack([bias[:i].reshape(i // 32, 32), bias[i:].reshape(i // 32, 32)], dim=1).reshape(two_i).contiguous()
+    return w, b
+
+
 def pack_geglu(weight, bias):
     """GEGLU projection ``weight`` [2I, K] / ``bias`` [2I] (value half, then gate half) -> operands of
     ``linear_geglu``: 32-row blocks of the two halves interleaved (v0, g0, v1, g1, ...), the weight in the conv
     kernel's packed [rows][1][K] layout."""
     two_i, k = weight.shape
-    i = two_i // 2
-    assert i % 128 == 0 and k % 64 == 0, (i, k)
-    w = torch.stack([weight[:i].reshape(i // 32, 32, k), weight[i:].reshape(i // 32, 32, k)], dim=1).reshape(two_i, k, 1, 1)
-    b = None
-    if bias is not None:
-        b = torch.stack([bias[:i].reshape(i // 32, 32), bias[i:].reshape(i // 32, 32)], dim=1).reshape(two_i).contiguous()
-    return pack_conv_weight(w.contiguous()), b
+    assert (two_i // 2) % 128 == 0 and k % 64 == 0, (two_i, k)
+    w, b = interleave_geglu(weight, bias)
+    return pack_conv_weight(w.reshape(two_i, k, 1, 1).contiguous()), b
 
 
 def linear_geglu(x, w_packed, bias_packed, inner):

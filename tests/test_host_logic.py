@@ -169,6 +169,31 @@ def test_pipeline_against_reference(mv):
     assert vid.dtype == torch.float32 and vid.shape == (1, 3, 16, 256, 512)
 
 
+def test_geglu_interleave_and_gemm_routing_rules():
+    """Host side of the fused GEMM paths: the value/gate row interleave that the GEGLU epilogue assumes (accumulator
+    blocks 2i / 2i+1 = value / gate of the same 32 channels), and the shape rules that route a Linear to the kernel."""
+    import torch.nn.functional as F
+    from imagine360_amd import kernels, layers
+    g = torch.Generator().manual_seed(3)
+    I, Kd = 256, 64
+    w, b = torch.randn(2 * I, Kd, generator=g), torch.randn(2 * I, generator=g)
+    wp, bp = kernels.interleave_geglu(w, b)
+    x = torch.randn(5, Kd, generator=g)
+    h = F.linear(x, wp, bp).reshape(5, I // 32, 2, 32)          # packed GEMM output: [.., block, value|gate, 32]
+    fused = (h[:, :, 0] * F.gelu(h[:, :, 1])).reshape(5, I)
+    ref = F.linear(x, w, b)
+    assert torch.allclose(fused, ref[:, :I] * F.gelu(ref[:, I:]), atol=1e-5)
+    # routing: level-0 / pers level-1 token counts of cfg2 take the kernel, deeper levels stay on hipBLASLt
+    assert layers._gemm_kernel_pays(655360, 320, 320) and layers._gemm_kernel_pays(262144, 320, 960)
+    assert layers._gemm_kernel_pays(163840, 2560, 640) and not layers._gemm_kernel_pays(40960, 5120, 1280)
+    assert not layers._gemm_kernel_pays(655360, 320, 256) and not layers._gemm_kernel_pays(655360, 96, 320)
+    # on CPU tensors the helpers are plain torch (the emulated product path of these tests)
+    lin = torch.nn.Linear(Kd, 32)
+    r = torch.randn(5, 32, generator=g)
+    assert torch.allclose(layers.linear_residual(lin, x, r), lin(x) + r)
+    assert torch.allclose(layers.linear(lin, x), lin(x))
+
+
 def test_no_cpu_fallback_in_product():
     from imagine360_amd import kernels
     x = torch.zeros(1, 16, 64)
