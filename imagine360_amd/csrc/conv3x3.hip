@@ -12,14 +12,16 @@
 // Epilogue fuses bias, the time-embedding add (resnet.py:231-234) and the residual/shortcut add
 // (resnet.py:248-251).
 //
-// GEMM view: D^T[cout, pixel] = W[cout, (tap, cin)] * X^T[(tap, cin), pixel]; 128 x 128 tile per
-// 256-thread workgroup, 4 waves as 2 x 2, each wave 2 x 2 v_mfma_f32_32x32x16 tiles (64 fp32
-// accumulators), K-step = BK channels of one tap.  Both operands go HBM/L2 -> LDS by LDS-DMA
+// The same kernel serves the large token-major nn.Linear layers as a 1x1 conv over a [M, 1, 1, K] view (bias and
+// residual in the epilogue; a GEGLU epilogue variant: im360_linear_geglu).
+//
+// GEMM view: D^T[cout, pixel] = W[cout, (tap, cin)] * X^T[(tap, cin), pixel]; tiles of WM x WN waves with TM x TN
+// v_mfma_f32_32x32x16 blocks each (see the template below), K-step = BK channels of one tap.  Both operands go HBM/L2 -> LDS by LDS-DMA
 // (global_load_lds, 16 B per lane, no VGPR staging): the taps' shifted / wrapped / upsampled pixel
 // addresses are per-lane SOURCE addresses, out-of-image taps read a 16-byte zero chunk, and the XOR
 // swizzle that keeps ds_read_b128 fragment reads conflict-free is applied on the source side (the DMA
 // destination is lane-linear).  Double-buffered LDS, one barrier per K-step: step s+1 streams in under
-// the 16 MFMAs of step s.
+// the MFMAs of step s.
 #include "common.h"
 
 namespace im360 {
@@ -33,7 +35,6 @@ struct ConvParams {
     long M;             // N * Hout * Wout
     int tiles_n;        // ceil(Cout / 128)
     long nblocks;
-    int dbg;            // tuning experiments only (IM360_CONV_DBG): 1 = skip the epilogue, 2 = skip the K loop
 };
 
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int ksteps_per_tap = p.Cin / BK;
-    const int nsteps = (p.dbg & 2) ? 0 : p.ntaps * ksteps_per_tap;
+    const int nsteps = p.ntaps * ksteps_per_tap;
 
     // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
     // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
@@ -210,17 +211,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
         });
     }
 
-    // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
-    //      lane would write 8 bytes at a pixel-row stride (32 rows x 16 B per instruction).  Instead each wave
-    //      transposes its tile through LDS (free after the K loop), 32 pixels at a time: bias / temb are added in
-    //      registers, the 16-bit rows are written to LDS, then read back row-major so consecutive lanes store (and
-    //      fetch the residual from) consecutive 8-byte pieces of one output row -- whole 128-byte lines.
+    // ---- epilogues
     const T* bias = (const T*)p.bias;
     const T* temb = (const T*)p.temb;
     const T* res = (const T*)p.res;
     T* yg = (T*)p.y;
     const int nw0 = n0 + wn * (TN * 32);          // first cout of this wave
-    if (p.dbg & 1) { if (acc[0][0][0] == 12345.f) ((T*)p.y)[0] = from_f32<T>(0.f); return; }
     // LDS transpose of one 32-pixel block of this wave: rows of ROWB bytes (TN or TN/2 blocks of 32 couts), unpadded
     // and 16-byte aligned; the 16-byte piece index is XORed with row bits and the two 8-byte halves of a piece are
     // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
@@ -407,8 +403,6 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         return IM360_ERR_ARG;
     }
     static const int bk_env = getenv("IM360_CONV_BK") ? atoi(getenv("IM360_CONV_BK")) : 0;   // tuning override
-    static const int dbg_env = getenv("IM360_CONV_DBG") ? atoi(getenv("IM360_CONV_DBG")) : 0;
-    p.dbg = dbg_env;
     constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI == 0;      // the 8-wave tiles are BK = 64 only
     if ((p.Cin % 64 == 0 && bk_env != 32) || !has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
