@@ -176,8 +176,13 @@ def main():
     if not args.no_graph:
         # the step is ~3000 launches: capture it once (hipGraph) and replay, so the host is out of the loop
         from imagine360_amd.graph_step import GraphedDenoiseStep
-        graphed = GraphedDenoiseStep(mv, sch, inp, cams, pano_lat, pers_lat, guidance, warmup=1)
-
+        try:
+            graphed = GraphedDenoiseStep(mv, sch, inp, cams, pano_lat, pers_lat, guidance, warmup=1)
+        except RuntimeError as e:           # capture refused (e.g. by another runtime thread): time the eager issue instead
+            print(f"[rank {rank}] hipGraph capture failed, falling back to eager launches: {e}", file=sys.stderr)
+            graphed = None
+            torch.cuda.synchronize()
+    if graphed is not None:
         def step(i):                                                       # noqa: F811
             graphed.step(ts_host[i % nsteps_total])
 

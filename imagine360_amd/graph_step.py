@@ -35,7 +35,8 @@ class GraphedDenoiseStep:
         self.graph = torch.cuda.CUDAGraph()
         mv.coins_preloaded = True
         try:
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: a RCCL watchdog / other host thread touching the runtime must not abort the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._body()
         finally:
             mv.coins_preloaded = False
