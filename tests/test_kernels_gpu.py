@@ -197,6 +197,26 @@ def test_conv3x3_256x320_tiles(dt, N, H, W, Cin, Cout, wrap):
     assert rel(out, ref) < TOL[dt]
 
 
+def test_conv3x3_256x320_tiles_addressing_modes():
+    """The stride-2 / nearest-upsample / pre-padded-window addressing modes at pixel counts that take the 8-wave
+    256 x 320 tile (the cfg2 Downsample3D / Upsample3D / pano conv2 launches), against the reference composition."""
+    dt = torch.bfloat16
+    C, Co = 64, 320
+    w = q16(rnd(Co, C, 3, 3, seed=71, scale=(9 * C) ** -0.5), dt)
+    b = q16(rnd(Co, seed=72, scale=0.1), dt)
+    wp, db = K.pack_conv_weight(w.to(dt).cuda()), b.to(dt).cuda()
+    x = q16(rnd(640, 32, 32, C, seed=73), dt)                       # stride 2: 640 x 16 x 16 outputs = 640 tiles
+    assert rel(K.conv2d(x.to(dt).cuda(), wp, Co, bias=db, stride=2), _conv_ref(x, w, b, stride=2)) < TOL[dt]
+    assert rel(K.conv2d(x.to(dt).cuda(), wp, Co, bias=db, stride=2, wrap=True),
+               _conv_ref(x, w, b, stride=2, wrap_pad=2, unpad=1)) < TOL[dt]
+    x = q16(rnd(128, 16, 16, C, seed=74), dt)                       # nearest x2: 128 x 32 x 32 outputs = 512 tiles
+    assert rel(K.conv2d(x.to(dt).cuda(), wp, Co, bias=db, up=True), _conv_ref(x, w, b, up=True)) < TOL[dt]
+    x = q16(rnd(64, 32, 64, C, seed=75), dt)                        # window of the W+4 padded tensor, 512 tiles
+    xp = OG.pad_pano(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).contiguous()
+    ref = OG.unpad_pano(F.conv2d(xp.permute(0, 3, 1, 2), w, b, padding=1), 2).permute(0, 2, 3, 1)
+    assert rel(K.conv2d(xp.to(dt).cuda(), wp, Co, bias=db, x_off=2, wout=64), ref) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_linear_residual_through_gemm_kernel(dt):
     """Token counts large enough for layers.linear_residual to take the implicit-GEMM kernel (bias + residual in the
