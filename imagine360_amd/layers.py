@@ -101,8 +101,9 @@ def layer_norm(norm, x, pre=None, post=None, post_div=1):
 def _gemm_kernel_pays(m, k, n):
     """Shapes where the implicit-GEMM conv kernel (as a 1x1 conv with its fused bias / residual epilogue) is at least
     as fast as hipBLASLt + a separate residual add: its 256 x 320 tiles need K % 64 == 0, N % 320 == 0 and enough
-    tiles to fill the chip a few times (measured with tools/bench_kernels.py linear)."""
-    return k % 64 == 0 and n % 320 == 0 and ((m + 255) // 256) * (n // 320) >= 1024
+    work to fill the chip -- measured (tools/bench_kernels.py linear): every level-0 / level-1 token
+    count of cfg2 (>= 65 536 tokens) wins or ties, the 40 960-token level-2 shapes lose to hipBLASLt's deep-K kernels."""
+    return k % 64 == 0 and n % 320 == 0 and m >= 65536 and ((m + 255) // 256) * (n // 320) >= 512
 
 
 def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1"):
@@ -146,8 +147,8 @@ class GEGLU(nn.Module):
         m = x.numel() // k
         # large token counts: projection, bias and the gated activation in ONE launch of the MFMA GEMM kernel (the
         # 2I-wide intermediate never goes to HBM); otherwise hipBLASLt + the elementwise kernel
-        # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 640 at >= 128k tokens, loses at K = 1280 / 40k)
-        if x.is_cuda and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= 131072:
+        # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 640 at >= 64k tokens, loses at K = 1280 / 40k)
+        if x.is_cuda and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= 65536:
             cache = _module_cache(self)
             ps = (self.proj.weight,) if self.proj.bias is None else (self.proj.weight, self.proj.bias)
             wp, bp = cache.get("geglu", ps, lambda: kernels.pack_geglu(self.proj.weight.detach(),
