@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -79,5 +81,36 @@ extern "C" int im360_prof_collect(int kind, double* total_ms, long* launches) {
     g_used.swap(keep);
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Knobs {
+    std::atomic<int> v[im360::KNOB_COUNT];
+    Knobs() {
+        static const struct { int k; const char* env; int def; } init[] = {
+            {im360::KNOB_ATTN_QB, "IM360_ATTN_QB", 0},       {im360::KNOB_CONV_BIG, "IM360_CONV_BIG", 1},
+            {im360::KNOB_CONV_BK, "IM360_CONV_BK", 0},       {im360::KNOB_TATTN_SCALAR, "IM360_TATTN_SCALAR", 0},
+            {im360::KNOB_CONV_RING, "IM360_CONV_RING", 1},
+        };
+        for (auto& x : v) x.store(0);
+        for (auto& i : init) {
+            const char* e = getenv(i.env);
+            v[i.k].store(e ? atoi(e) : i.def);
+        }
+    }
+};
+Knobs g_knobs;
+}  // namespace
+
+int im360::knob(int k) { return (k >= 0 && k < im360::KNOB_COUNT) ? g_knobs.v[k].load(std::memory_order_relaxed) : 0; }
+
+extern "C" int im360_tuning_set(int knob, int value) {
+    if (knob < 0 || knob >= im360::KNOB_COUNT) {
+        im360_set_error("tuning_set: unknown knob %d", knob);
+        return -1;
+    }
+    g_knobs.v[knob].store(value);
     return 0;
 }

@@ -347,7 +347,7 @@ template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
     // two query blocks per wave once that still leaves every CU several workgroups
-    static const int qb_env = getenv("IM360_ATTN_QB") ? atoi(getenv("IM360_ATTN_QB")) : 0;   // tuning override
+    const int qb_env = knob(KNOB_ATTN_QB);       // tuning override
     int qb = (D == 32 && nw == 4 && p.Nq >= 256 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 1024) ? 2 : 1;   // d = 64 spills at QB = 2
     if (qb_env && nw == 4) qb = qb_env == 2 ? 2 : 1;
     p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);

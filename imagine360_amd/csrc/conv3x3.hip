@@ -41,6 +41,214 @@ struct ConvParams {
 // 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
 __device__ uint4 g_zero_chunk[1];
 
+// ---- epilogue shared by the tile kernels.  `lds` is a region of at least (waves * 32 * row bytes) that no wave reads
+//      as operand tiles any more; the caller has passed a workgroup barrier since the last operand read.
+template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false>
+__device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
+                                              int wm, int wn, int wid_s, int lane) {
+    const int col = lane & 31, hi = lane >> 5;
+    const T* bias = (const T*)p.bias;
+    const T* temb = (const T*)p.temb;
+    const T* res = (const T*)p.res;
+    T* yg = (T*)p.y;
+    const int nw0 = n0 + wn * (TN * 32);          // first cout of this wave
+    // LDS transpose of one 32-pixel block of this wave: rows of ROWB bytes (TN or TN/2 blocks of 32 couts), unpadded
+    // and 16-byte aligned; the 16-byte piece index is XORed with row bits and the two 8-byte halves of a piece are
+    // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
+    // different bank pairs (checked exhaustively for 320- and 128-byte rows).  The row-major side reads whole pieces.
+    auto piece_xor = [](int row, int rowb) { return rowb == 128 ? (row & 7) : ((row >> 1) & 3); };
+    if constexpr (EPI == 1) {
+        // GEGLU epilogue (token-major linear only): the packed weight rows alternate 32 value rows / 32 gate rows of the
+        // same output channels, so accumulators (2i, 2i+1) hold value and gate of one channel in the same lane and
+        // register: out = (value + b) * gelu(gate + b), half as many columns as the GEMM is wide.
+        static_assert(TN % 2 == 0, "value / gate blocks come in pairs");
+        constexpr int ROWB = (TN / 2) * 64;
+        constexpr int PIECES = ROWB / 16;
+        static_assert(ROWB == 128, "swizzle pattern");
+        const int I = p.Cout / 2;
+        const int ow0 = nw0 / 2;                  // first output channel of this wave
+        char* wlds = lds + wid_s * (32 * ROWB);
+        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
+        const T* gb = bias ? bias : (const T*)g_zero_chunk;      // unconditional bias loads (see the plain epilogue)
+        const int gbmul = bias ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const long mb = m0 + wm * (TM * 32) + b * 32;
+#pragma unroll
+            for (int i = 0; i < TN / 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows (bias index)
+                    float v[4], t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = acc[2 * i][b][4 * g + j]; t[j] = acc[2 * i + 1][b][4 * g + j]; }
+                    {
+                        const uint2 wv = *(const uint2*)(gb + rv * gbmul), wg = *(const uint2*)(gb + rg * gbmul);
+                        v[0] += unpack_lo<T>(wv.x); v[1] += unpack_hi<T>(wv.x); v[2] += unpack_lo<T>(wv.y); v[3] += unpack_hi<T>(wv.y);
+                        t[0] += unpack_lo<T>(wg.x); t[1] += unpack_hi<T>(wg.x); t[2] += unpack_lo<T>(wg.y); t[3] += unpack_hi<T>(wg.y);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the unfused path rounds the projection to 16 bits before the activation: keep that rounding
+                        const float vr = to_f32(from_f32<T>(v[j])), tr = to_f32(from_f32<T>(t[j]));
+                        v[j] = vr * gelu_erf_fast(tr);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(v[0], v[1]);
+                    o.y = pack2<T>(v[2], v[3]);
+                    *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (32 * PIECES + 63) / 64; ++it) {
+                const int f = it * 64 + lane;
+                const int row = f / PIECES, pc = f % PIECES;
+                const long mr = mb + row;
+                const int co = ow0 + pc * 8;
+                if (row < 32 && mr < p.M && co < I) {
+                    uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
+                    if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
+                    *(uint4*)(yg + mr * I + co) = o;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    } else {
+    // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
+    //      lane would write 8 bytes at a pixel-row stride (32 rows x 16 B per instruction).  Instead each wave
+    //      transposes its tile through LDS (free after the K loop), 32 pixels at a time: bias / temb are added in
+    //      registers, the 16-bit rows are written to LDS, then read back row-major so consecutive lanes store (and
+    //      fetch the residual from) consecutive 16-byte pieces of one output row -- whole 128-byte lines.
+    if (COUT8 || (p.Cout & 7) == 0) {
+        constexpr int ROWB = TN * 64;
+        constexpr int PIECES = ROWB / 16;
+        static_assert(ROWB == 128 || ROWB == 320, "swizzle pattern");
+        static_assert((32 * PIECES) % 64 == 0, "store rounds cover the block exactly");
+        char* wlds = lds + wid_s * (32 * ROWB);
+        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
+        // Every global load of the epilogue is UNCONDITIONAL: an absent operand (no bias / temb / residual) reads the
+        // 16-byte zero chunk with a zero index multiplier, out-of-range rows / couts are clamped into the tensor (their
+        // results are never stored).  A load behind a per-lane or per-operand branch makes hipcc wait vmcnt(0) at every
+        // use -- and since stores count in vmcnt too, that serialised the ten store rounds of a block behind each other.
+        // Addresses are a wave-uniform 64-bit base (block row 0) + a 32-bit per-lane byte offset: ten 64-bit load and ten
+        // 64-bit store addresses per block would otherwise be kept live (and spilled) next to the accumulators.
+        const char* zsrc = (const char*)g_zero_chunk;
+        const char* bsrc = bias ? (const char*)bias : zsrc;
+        const char* tsrc = temb ? (const char*)temb : zsrc;
+        const uint32_t bmul = bias ? 2u : 0u, tmul = temb ? 2u : 0u, rmul = res ? 2u : 0u;      // bytes per element, or 0
+        const int cmax4 = p.Cout - 4, cmax8 = p.Cout - 8;
+        const long hw = (long)p.Hout * p.Wout;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block (wave-uniform)
+            if (mb >= p.M) continue;
+            const int rows = p.M - mb < 32 ? (int)(p.M - mb) : 32;  // valid rows of the block
+            const char* rbase = res ? (const char*)(res + mb * p.Cout) : zsrc;
+            char* ybase = (char*)(yg + mb * p.Cout);
+            const long m = mb + (col < rows ? col : rows - 1);
+            const uint32_t toff = (uint32_t)((m / hw) / p.imgs_per_temb) * (uint32_t)p.Cout;   // temb row of this lane's pixel
+            // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
+            // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
+            constexpr int NIT = (32 * PIECES) / 64, NIT1 = NIT / 2;
+            u32x4 rv[NIT];
+            auto piece_off = [&](int it, bool& ok) {      // element offset of this lane's piece in round `it` (clamped into the block)
+                const int f = it * 64 + lane;
+                const int row = f / PIECES, co = nw0 + (f % PIECES) * 8;
+                ok = row < rows && co < p.Cout;
+                return (uint32_t)((row < rows ? row : rows - 1) * p.Cout + (co < cmax8 ? co : cmax8));
+            };
+            auto load_res = [&](int it0, int it1) {
+#pragma unroll
+                for (int it = it0; it < it1; ++it) {
+                    bool ok;
+                    rv[it] = *(const u32x4*)(rbase + piece_off(it, ok) * rmul);
+                }
+            };
+            load_res(0, NIT1);
+            __builtin_amdgcn_sched_barrier(0);    // (hipcc would hoist every load of the block up here and spill)
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                uint2 wb[4], wt[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = nw0 + a * 32 + 8 * g + 4 * hi;
+                    const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
+                    wb[g] = *(const uint2*)(bsrc + cc * bmul);
+                    if constexpr (EPI != 2) wt[g] = *(const uint2*)(tsrc + (toff + cc) * tmul);      // (token-major linears have no temb)
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float f[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
+                    f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
+                    if constexpr (EPI != 2) {
+                        f[0] += unpack_lo<T>(wt[g].x); f[1] += unpack_hi<T>(wt[g].x); f[2] += unpack_lo<T>(wt[g].y); f[3] += unpack_hi<T>(wt[g].y);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(f[0], f[1]);
+                    o.y = pack2<T>(f[2], f[3]);
+                    *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_res(NIT1, NIT);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = it * 64 + lane;
+                const int row = f / PIECES, pc = f % PIECES;
+                uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
+                if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
+                const u32x4 w = rv[it];
+                o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
+                o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
+                o.z = pack2<T>(unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z));
+                o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
+                bool ok;
+                const uint32_t off = piece_off(it, ok);
+                if (ok) *(uint4*)(ybase + off * 2u) = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
+        }
+        return;
+    }
+    // Cout not a multiple of 8 (conv_out's 4 channels, odd test shapes): stores straight from the fragments
+    if constexpr (!COUT8) {
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const long m = m0 + wm * (TM * 32) + b * 32 + col;
+        if (m >= p.M) continue;
+        const long img = m / ((long)p.Hout * p.Wout);
+        const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = nw0 + a * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (co + j < p.Cout) {
+                        float vv = acc[a][b][4 * g + j];
+                        if (bias) vv += to_f32(bias[co + j]);
+                        if (trow) vv += to_f32(trow[co + j]);
+                        if (res) vv += to_f32(res[m * p.Cout + co + j]);
+                        yg[m * p.Cout + co + j] = from_f32<T>(vv);
+                    }
+                }
+            }
+        }
+    }
+    }
+    }
+}
+
 // WM x WN waves, each owning TM x TN blocks of 32 pixels x 32 couts:
 //   (2, 2, 2, 2) = 128 pixels x 128 couts, 4 waves     -- small problems, odd Cout
 //   (4, 1, 2, 2) = 256 pixels x 64 couts, 4 waves      -- Cout that leaves a half-empty last 128-tile
@@ -211,185 +419,256 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
         });
     }
 
-    // ---- epilogues
-    const T* bias = (const T*)p.bias;
-    const T* temb = (const T*)p.temb;
-    const T* res = (const T*)p.res;
-    T* yg = (T*)p.y;
-    const int nw0 = n0 + wn * (TN * 32);          // first cout of this wave
-    // LDS transpose of one 32-pixel block of this wave: rows of ROWB bytes (TN or TN/2 blocks of 32 couts), unpadded
-    // and 16-byte aligned; the 16-byte piece index is XORed with row bits and the two 8-byte halves of a piece are
-    // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
-    // different bank pairs (checked exhaustively for 320- and 128-byte rows).  The row-major side reads whole pieces.
-    auto piece_xor = [](int row, int rowb) { return rowb == 128 ? (row & 7) : ((row >> 1) & 3); };
-    if constexpr (EPI == 1) {
-        // GEGLU epilogue (token-major linear only): the packed weight rows alternate 32 value rows / 32 gate rows of the
-        // same output channels, so accumulators (2i, 2i+1) hold value and gate of one channel in the same lane and
-        // register: out = (value + b) * gelu(gate + b), half as many columns as the GEMM is wide.
-        static_assert(TN % 2 == 0, "value / gate blocks come in pairs");
-        constexpr int ROWB = (TN / 2) * 64;
-        constexpr int PIECES = ROWB / 16;
-        static_assert(ROWB == 128, "swizzle pattern");
-        const int I = p.Cout / 2;
-        const int ow0 = nw0 / 2;                  // first output channel of this wave
-        __syncthreads();
-        char* wlds = lds + wid_s * (32 * ROWB);
-        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
+    static_assert((NT / 64) * 32 * (EPI == 1 ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
+    __syncthreads();                              // every wave is done reading the operand tiles
+    tile_epilogue<T, NT, TM, TN, EPI>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
+}
+
+// One 16-byte-per-lane LDS-DMA load issued from inline asm: `lds_dst` is the wave-uniform LDS byte address of the KiB the
+// wave fills (lane-linear), `gsrc` each lane's source.  hipcc models the builtin form as a pending LDS access of unknown
+// order, which turns every ds_read wait of the kernel into lgkmcnt(0); hidden in asm, fragment reads get counted waits.
+// The asm loads are absent from hipcc's vmcnt bookkeeping: the kernel waits for them itself (counted vmcnt + barrier),
+// and hidden loads can only make hipcc's own waits stricter (completion is in order).  M0 is compiler-reserved and not
+// preserved around a statement, so it is saved and restored inside.
+__device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
+// The kernel above keeps two LDS stages of 64 channels and drains the LDS-DMA queue at every step (one barrier per step,
+// vmcnt(0) in front of it): with one workgroup per CU a step lasts as long as its stage takes to arrive (2.7 us measured
+// against 1.07 us of MFMA work), and the epilogue of a tile overlaps nothing.  Here
+//   * the K loop runs in PHASES of 32 channels over a ring of 4 LDS slots; phase q is requested three phases ahead, the
+//     wait in front of phase q's barrier is a COUNTED vmcnt that leaves the two younger phases in flight, so a stage has
+//     1.5 steps of MFMA time to arrive instead of one and the queue never drains inside a tile;
+//   * workgroups are persistent (one per CU) and walk the tiles in an XCD-aware order; before the epilogue of a tile the
+//     first two phases of the NEXT tile are requested into ring slots 0 / 1 (the epilogue's LDS transpose lives in
+//     slots 2 / 3), so the operand stream keeps flowing while accumulators are converted and stored.
+// Accumulation order over K is the same as in the kernel above (16 channels per MFMA, ascending), so results are
+// bit-identical.
+template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
+    constexpr int NT = 512, WN = 2, TM = 2;
+    constexpr int BM = 256, BN = WN * TN * 32, BK = 32;
+    constexpr int CPR = BK / 8, ROWB = BK * 2, RPB = 256 / ROWB;      // 4 chunks per 64-byte row, 4 rows per bank row
+    constexpr int KC = BK / 16;
+    constexpr int NSLOT = 4;
+    constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB, SLOT = TILE_A + TILE_B;
+    constexpr int LDA = (BM * CPR) / NT;                  // 2 LDS-DMA loads per thread per phase: activations
+    constexpr int LDB = (BN * CPR) / NT;                  // 2 full rounds of weights ...
+    constexpr bool B_TAIL = (BN * CPR) % NT != 0;         // ... + half a round (waves 0..3) when BN = 320
+    static_assert((BM * CPR) % NT == 0 && ((BN * CPR) % NT == 0 || (BN * CPR) % NT == NT / 2), "staging pattern");
+    constexpr int EPI_ROWB = EPI == 1 ? (TN / 2) * 64 : TN * 64;
+    constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
+    constexpr int LDS_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const int Hc = p.up ? 2 * p.Hin : p.Hin, Wc = p.up ? 2 * p.Win : p.Win;
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+    const T* zero = (const T*)g_zero_chunk;
+
+    // persistent tile walk: block b sits on XCD b % 8 (observed dispatch order; only speed depends on it).  Round `it`
+    // covers gridDim.x consecutive logical tiles, XCD x takes the x-th eighth of them: the tiles in flight on one XCD are
+    // neighbours (same pixel rows / neighbouring cout tiles), the chip as a whole works on one contiguous range.
+    const long ntiles = p.nblocks;
+    const int per_xcd = gridDim.x / 8;
+    const long tile_first = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const long tile_step = gridDim.x;
+
+    constexpr int RPI = NT / CPR;               // 128 tile rows between a thread's consecutive chunks
+    const int srow = tid / CPR;
+    const int pd8 = ((tid % CPR) ^ ((srow / RPB) & (CPR - 1))) * 8;        // data chunk (elements) stored at this LDS position
+    const int ksteps_per_tap = p.Cin / BK;
+    const int nph = p.ntaps * ksteps_per_tap;
+
+    // ---- producer state (LDS-DMA stream of ONE tile; re-initialised for the next tile as soon as this tile's last
+    //      phase has been requested)
+    uint32_t pyx[LDA], pnv[LDA];
+    const T* aptr[LDA];
+    uint32_t amask = 0;
+    const T* bptr = wg;
+    const long bstride = (long)RPI * p.ntaps * p.Cin;
+    int tap_p = 0, kk_p = 0;
+    auto set_tap = [&](int tap) {
+        const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const long mb = m0 + wm * (TM * 32) + b * 32;
-#pragma unroll
-            for (int i = 0; i < TN / 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows (bias index)
-                    float v[4], t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = acc[2 * i][b][4 * g + j]; t[j] = acc[2 * i + 1][b][4 * g + j]; }
-                    if (bias) {
-                        const uint2 wv = *(const uint2*)(bias + rv), wg = *(const uint2*)(bias + rg);
-                        v[0] += unpack_lo<T>(wv.x); v[1] += unpack_hi<T>(wv.x); v[2] += unpack_lo<T>(wv.y); v[3] += unpack_hi<T>(wv.y);
-                        t[0] += unpack_lo<T>(wg.x); t[1] += unpack_hi<T>(wg.x); t[2] += unpack_lo<T>(wg.y); t[3] += unpack_hi<T>(wg.y);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // the unfused path rounds the projection to 16 bits before the activation: keep that rounding
-                        const float vr = to_f32(from_f32<T>(v[j])), tr = to_f32(from_f32<T>(t[j]));
-                        v[j] = vr * gelu_erf_fast(tr);
-                    }
-                    uint2 o;
-                    o.x = pack2<T>(v[0], v[1]);
-                    o.y = pack2<T>(v[2], v[3]);
-                    *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < (32 * PIECES + 63) / 64; ++it) {
-                const int f = it * 64 + lane;
-                const int row = f / PIECES, pc = f % PIECES;
-                const long mr = mb + row;
-                const int co = ow0 + pc * 8;
-                if (row < 32 && mr < p.M && co < I) {
-                    uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
-                    if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
-                    *(uint4*)(yg + mr * I + co) = o;
-                }
+        for (int i = 0; i < LDA; ++i) {
+            int gy = (int)(pyx[i] & 0xffffu) * p.stride + dy - 1 + p.y_off;
+            int gx = (int)(pyx[i] >> 16) * p.stride + dx - 1 + p.x_off;
+            bool ok = (pnv[i] >> 31) && gy >= 0 && gy < Hc;
+            if (p.wrap) {
+                gx = gx < 0 ? gx + Wc : (gx >= Wc ? gx - Wc : gx);
+            } else {
+                ok = ok && gx >= 0 && gx < Wc;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            const int sy = gy >> p.up, sx = gx >> p.up;
+            const long off = ok ? (((long)(pnv[i] & 0x7fffffffu) * p.Hin + sy) * p.Win + sx) * p.Cin + pd8 : 0;
+            aptr[i] = ok ? xg + off : zero;
+            amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
         }
-        return;
-    } else {
-    // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
-    //      lane would write 8 bytes at a pixel-row stride (32 rows x 16 B per instruction).  Instead each wave
-    //      transposes its tile through LDS (free after the K loop), 32 pixels at a time: bias / temb are added in
-    //      registers, the 16-bit rows are written to LDS, then read back row-major so consecutive lanes store (and
-    //      fetch the residual from) consecutive 16-byte pieces of one output row -- whole 128-byte lines.
-    if ((p.Cout & 7) == 0) {
-        constexpr int ROWB = TN * 64;
-        constexpr int PIECES = ROWB / 16;
-        static_assert(ROWB == 128 || ROWB == 320, "swizzle pattern");
-        static_assert(NT / 64 * 32 * ROWB <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
-        __syncthreads();                          // every wave is done reading the operand tiles
-        char* wlds = lds + wid_s * (32 * ROWB);
-        const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
+    };
+    auto init_tile = [&](long tile) {
+        const long m0 = (tile / p.tiles_n) * BM;
+        const int n0 = (int)(tile % p.tiles_n) * BN;
+        bptr = wg + (long)(n0 + srow) * p.ntaps * p.Cin + pd8;
+        tap_p = 0;
+        kk_p = 0;
+        if constexpr (LINEAR) {
 #pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block
-            const long m = mb + col;
-            const long img = (m < p.M ? m : p.M - 1) / ((long)p.Hout * p.Wout);
-            const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
-            // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
-            // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
-            constexpr int NIT = (32 * PIECES + 63) / 64, NIT1 = NIT / 2;
-            u32x4 rv[NIT];
-            auto load_res = [&](int it0, int it1) {
+            for (int i = 0; i < LDA; ++i) {
+                const long m = m0 + srow + i * RPI;
+                const bool ok = m < p.M;
+                aptr[i] = ok ? xg + m * p.Cin + pd8 : zero;
+                amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
+            }
+        } else {
 #pragma unroll
-                for (int it = it0; it < it1; ++it) {
-                    const int f = it * 64 + lane;
-                    const int row = f / PIECES, pc = f % PIECES;
-                    const long mr = mb + row;
-                    const int co = nw0 + pc * 8;
-                    rv[it] = u32x4{0u, 0u, 0u, 0u};
-                    if (res && row < 32 && mr < p.M && co < p.Cout) rv[it] = *(const u32x4*)(res + mr * p.Cout + co);
-                }
-            };
-            load_res(0, NIT1);
+            for (int i = 0; i < LDA; ++i) {
+                const long m = m0 + srow + i * RPI;
+                const bool valid = m < p.M;
+                const long mm = valid ? m : 0;
+                const long t = mm / p.Wout;
+                pyx[i] = (uint32_t)(t % p.Hout) | ((uint32_t)(mm % p.Wout) << 16);
+                pnv[i] = (uint32_t)(t / p.Hout) | (valid ? 0x80000000u : 0u);
+            }
+            set_tap(0);
+        }
+    };
+    const uint32_t lds_u32 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
+    auto dma = [&](const T* src, int off) {       // off: byte offset inside the LDS array (wave-uniform)
+        if constexpr (ASM_DMA) {
+            lds_dma16_asm(src, lds_u32 + (uint32_t)off);
+        } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int slot) {
+        const int abase = slot * SLOT + wid_s * 1024;
+        const int bbase = abase + TILE_A;
+#pragma unroll
+        for (int i = 0; i < LDA; ++i) {
+            dma(aptr[i], abase + i * (NT * 16));
+            aptr[i] += ((amask >> i) & 1u) ? BK : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < LDB; ++i) dma(bptr + i * bstride, bbase + i * (NT * 16));
+        if constexpr (B_TAIL) {
+            // rows 256 .. 319 of the weight tile: one more KiB for each of the first four waves
+            if (wid_s < NT / 128) dma(bptr + LDB * bstride, bbase + LDB * (NT * 16));
+        }
+        bptr += BK;
+        if constexpr (!LINEAR) {
+            if (++kk_p == ksteps_per_tap) {
+                kk_p = 0;
+                if (++tap_p < p.ntaps) set_tap(tap_p);
+            }
+        }
+    };
+    // counted wait: at most `k` (0, 1, 2) of this wave's most recently requested phases may still be in flight.  The
+    // count is an immediate, the per-phase number of LDS-DMA instructions differs between the wave halves (B_TAIL).
+    auto wait_inflight = [&](int k) {
+        constexpr int N0 = LDA + LDB;
+        if (B_TAIL && wid_s < NT / 128) {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (N0 + 1)) : "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0 + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N0) : "memory");
+            else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    // fragment byte offsets inside a slot (see the kernel above): row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16)
+    const int swz = (col / RPB) & (CPR - 1);
+    int koff[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) koff[kc] = ((kc * 2 + hi) ^ swz) * 16;
+    const int wrow = (wn * (TN * 32) + col) * ROWB + TILE_A, xrow = (wm * (TM * 32) + col) * ROWB;
+
+    long tile = tile_first;
+    if (tile >= ntiles) return;
+    init_tile(tile);
+    issue(0);
+    if (nph > 1) issue(1);
+    for (;;) {
+        const long m0 = (tile / p.tiles_n) * BM;
+        const int n0 = (int)(tile % p.tiles_n) * BN;
+        // phase 2 goes into a slot the previous tile's epilogue used: every wave has to be out of it
+        asm volatile("s_barrier" ::: "memory");
+        if (nph > 2) issue(2);
+
+        f32x16 acc[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        for (int ph = 0; ph < nph; ++ph) {
+            // phase 0 also waits for whatever the previous tile's epilogue left in the queue (its stores sit between
+            // the prefetched phases 0 / 1 and phase 2)
+            const int rem = nph - 1 - ph;
+            wait_inflight(ph == 0 ? (rem >= 2 ? 1 : 0) : (rem >= 2 ? 2 : rem));
+            asm volatile("s_barrier" ::: "memory");      // phase ph landed for every wave; slot (ph + 3) & 3 is free again
+            if (ph + 3 < nph) issue((ph + 3) & (NSLOT - 1));
+            const char* at = lds + (ph & (NSLOT - 1)) * SLOT;
+            // fragment reads of the second 16-channel chunk are issued behind the first chunk's (its last weight
+            // fragments behind the first MFMAs), which caps the live fragment registers at 44 of the 256
+            static_assert(KC == 2, "two chunks per phase");
+            constexpr int EARLY = TN >= 4 ? TN - 2 : TN;
+            u32x4 xf[KC][TM], wf[KC][TN];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[0][b] = *(const u32x4*)(at + xrow + koff[0] + b * (32 * ROWB));
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[0][a] = *(const u32x4*)(at + wrow + koff[0] + a * (32 * ROWB));
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[1][b] = *(const u32x4*)(at + xrow + koff[1] + b * (32 * ROWB));
+#pragma unroll
+            for (int a = 0; a < EARLY; ++a) wf[1][a] = *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = nw0 + a * 32 + 8 * g + 4 * hi;
-                    const bool in = co < p.Cout;
-                    float f[4];
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[0][a]), __builtin_bit_cast(uint4, xf[0][b]), acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
-                    if (bias && in) {
-                        const uint2 w = *(const uint2*)(bias + co);
-                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
-                    }
-                    if (trow && in) {
-                        const uint2 w = *(const uint2*)(trow + co);
-                        f[0] += unpack_lo<T>(w.x); f[1] += unpack_hi<T>(w.x); f[2] += unpack_lo<T>(w.y); f[3] += unpack_hi<T>(w.y);
-                    }
-                    uint2 o;
-                    o.x = pack2<T>(f[0], f[1]);
-                    o.y = pack2<T>(f[2], f[3]);
-                    *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
-                }
-            load_res(NIT1, NIT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int a = EARLY; a < TN; ++a) wf[1][a] = *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int f = it * 64 + lane;
-                const int row = f / PIECES, pc = f % PIECES;
-                const long mr = mb + row;
-                const int co = nw0 + pc * 8;
-                if (row < 32 && mr < p.M && co < p.Cout) {
-                    uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
-                    if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
-                    if (res) {
-                        const u32x4 w = rv[it];
-                        o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
-                        o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
-                        o.z = pack2<T>(unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z));
-                        o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
-                    }
-                    *(uint4*)(yg + mr * p.Cout + co) = o;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[1][a]), __builtin_bit_cast(uint4, xf[1][b]), acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        return;
-    }
-    // Cout not a multiple of 8 (conv_out's 4 channels, odd test shapes): stores straight from the fragments
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const long m = m0 + wm * (TM * 32) + b * 32 + col;
-        if (m >= p.M) continue;
-        const long img = m / ((long)p.Hout * p.Wout);
-        const T* trow = temb ? temb + (img / p.imgs_per_temb) * p.Cout : nullptr;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = nw0 + a * 32 + 8 * g + 4 * hi;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (co + j < p.Cout) {
-                        float vv = acc[a][b][4 * g + j];
-                        if (bias) vv += to_f32(bias[co + j]);
-                        if (trow) vv += to_f32(trow[co + j]);
-                        if (res) vv += to_f32(res[m * p.Cout + co + j]);
-                        yg[m * p.Cout + co + j] = from_f32<T>(vv);
-                    }
-                }
-            }
+        asm volatile("s_barrier" ::: "memory");          // every wave is done reading operand slots
+        const long next = tile + tile_step;
+        if (next < ntiles) {                             // keep the operand stream going under the epilogue
+            init_tile(next);
+            issue(0);
+            if (nph > 1) issue(1);
         }
-    }
+        // the epilogue's per-lane addressing (rows / pieces / swizzles of ten store rounds) is invariant across tiles: keep
+        // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
+        int lane_e = lane, wid_e = wid_s;
+        asm volatile("" : "+v"(lane_e), "+s"(wid_e));
+        tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e);
+        if (next >= ntiles) break;
+        tile = next;
     }
 }
 
@@ -402,7 +681,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         im360_set_error("conv_fwd: problem too large");
         return IM360_ERR_ARG;
     }
-    static const int bk_env = getenv("IM360_CONV_BK") ? atoi(getenv("IM360_CONV_BK")) : 0;   // tuning override
+    const int bk_env = knob(KNOB_CONV_BK);       // tuning override
     constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI == 0;      // the 8-wave tiles are BK = 64 only
     if ((p.Cin % 64 == 0 && bk_env != 32) || !has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -413,12 +692,34 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     return IM360_OK;
 }
 
+// persistent ring kernel: one workgroup per CU (its LDS footprint allows no second one), grid a multiple of 8 (XCDs)
+template <typename T, int TN, int EPI, bool LINEAR>
+static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
+    constexpr int BM = 256, BN = 2 * TN * 32;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n >= 8 ? n / 8 * 8 : 8;
+    }();
+    const long want = (p.nblocks + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(want < ncu ? want : ncu);
+    if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true>), dim3(grid), dim3(512), 0, stream, p);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
 template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-    static const int big_env = getenv("IM360_CONV_BIG") ? atoi(getenv("IM360_CONV_BIG")) : 1;   // tuning override
+    const int big_env = knob(KNOB_CONV_BIG);           // tuning overrides
+    const int ring_env = knob(KNOB_CONV_RING);
     // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
     if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
-        if (p.ntaps == 1 && p.Hin == 1 && p.Win == 1) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
+        const bool linear = p.ntaps == 1 && p.Hin == 1 && p.Win == 1 && !p.temb;       // EPI 2 has no temb add
+        if (ring_env) return linear ? launch_ring_t<T, 5, 2, true>(p, stream, ring_env) : launch_ring_t<T, 5, 0, false>(p, stream, ring_env);
+        if (linear) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
         return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
     }
     // a last 128-wide cout tile that is at most half full wastes MFMA work: use 256 x 64 tiles instead
@@ -495,6 +796,10 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     IM360_CHECK_ARG(M <= 0x7fffffffL, "linear_geglu: M too large");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
+    if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
+        if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, knob(KNOB_CONV_RING));
+        if (dtype == 1) return launch_ring_t<_Float16, 4, 1, true>(p, s, knob(KNOB_CONV_RING));
+    }
     if (dtype == 0) return launch_conv_t<__bf16, 4, 2, 2, 4, 1>(p, s);
     if (dtype == 1) return launch_conv_t<_Float16, 4, 2, 2, 4, 1>(p, s);
     im360_set_error("linear_geglu: dtype %d unsupported", dtype);

@@ -69,29 +69,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 }
 
 // ---- pass 2 -----------------------------------------------------------------------------------
+// one wave per (image, group): the S x (C / G) partial sums of a group are read ONCE (coalesced over the group's
+// channels), reduced in fp64 across the wave, and the wave writes scale / shift of the group's channels.
 template <typename T>
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, const T* __restrict__ gamma,
-                                   const T* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
-                                   int N, int C, int G, int S, double count, float eps) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)N * C) return;
-    const int n = (int)(i / C), c = (int)(i % C);
-    const int cpg = C / G, g = c / cpg;
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, const T* __restrict__ gamma,
+                                                         const T* __restrict__ beta, float* __restrict__ scale,
+                                                         float* __restrict__ shift, int N, int C, int G, int S,
+                                                         double count, float eps) {
+    const int n = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
+    const int cpg = C / G;
     double sum = 0.0, sq = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const float* src = partial + ((long)(n * S + s) * 2) * C + g * cpg;
-        for (int j = 0; j < cpg; ++j) {
-            sum += (double)src[j];
-            sq += (double)src[C + j];
-        }
+    const float* base = partial + (long)n * S * 2 * C + g * cpg;
+    for (int i = lane; i < S * cpg; i += 64) {
+        const int s = i / cpg, j = i % cpg;
+        const float* src = base + (long)s * 2 * C + j;
+        sum += (double)src[0];
+        sq += (double)src[C];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        sq += __shfl_xor(sq, o);
     }
     const double mean = sum / count;
     double var = sq / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
-    scale[i] = (float)(rstd * ga);
-    shift[i] = (float)(be - mean * rstd * ga);
+    for (int j = lane; j < cpg; j += 64) {
+        const int c = g * cpg + j;
+        const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
+        scale[(long)n * C + c] = (float)(rstd * ga);
+        shift[(long)n * C + c] = (float)(be - mean * rstd * ga);
+    }
 }
 
 // ---- pass 3 -----------------------------------------------------------------------------------
@@ -207,17 +216,17 @@ extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const voi
     const double count = (double)H * (double)(W + 2 * pad) * (double)(C / G);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GN_STATS, stream);
-    const unsigned fb = (unsigned)((N * C + 255) / 256);
+    const unsigned fb = (unsigned)(N * G);
     if (dtype == 0) {
         hipLaunchKernelGGL((gn_partial_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const __bf16*)x,
                            (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
-        hipLaunchKernelGGL((gn_finalize_kernel<__bf16>), dim3(fb), dim3(256), 0, s, (const float*)partial,
+        hipLaunchKernelGGL((gn_finalize_kernel<__bf16>), dim3(fb), dim3(64), 0, s, (const float*)partial,
                            (const __bf16*)gamma, (const __bf16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
                            (int)G, S, count, eps);
     } else if (dtype == 1) {
         hipLaunchKernelGGL((gn_partial_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const _Float16*)x,
                            (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
-        hipLaunchKernelGGL((gn_finalize_kernel<_Float16>), dim3(fb), dim3(256), 0, s, (const float*)partial,
+        hipLaunchKernelGGL((gn_finalize_kernel<_Float16>), dim3(fb), dim3(64), 0, s, (const float*)partial,
                            (const _Float16*)gamma, (const _Float16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
                            (int)G, S, count, eps);
     } else {
@@ -265,8 +274,9 @@ extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "circular_pad_w: misaligned pointer");
     const long total = rows * (W + 2 * pad) * (C / 8);
     const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL((circular_pad_w_kernel<__bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x, (__bf16*)y, (long)rows, (int)W, (int)(C / 8), (int)pad);
+    // a byte copy of 16-bit elements: one instantiation serves both dtypes
+    hipLaunchKernelGGL((circular_pad_w_kernel<uint16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, (long)rows, (int)W, (int)(C / 8), (int)pad);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -217,7 +217,7 @@ static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
 
 template <typename T>
 static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
-    static const int scalar_env = getenv("IM360_TATTN_SCALAR") ? atoi(getenv("IM360_TATTN_SCALAR")) : 0;   // tuning override
+    const int scalar_env = knob(KNOB_TATTN_SCALAR);   // tuning override
     if (p.F <= 16 && !scalar_env) {
         int hpb = p.heads;                               // heads per workgroup: ~32 KB of LDS rows (3 * hpb * d <= 1248 channels)
         while (hpb > 1 && (hpb % 2) == 0 && hpb * p.d > 416) hpb /= 2;

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
     "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
     "im360_linear_geglu": (_INT, [_PTR] * 4 + [_I64] * 3 + [_INT, _PTR]),
+    "im360_tuning_set": (_INT, [_INT, _INT]),
     "im360_prof_enable": (None, [ctypes.c_uint]),
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
@@ -288,6 +289,16 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
                                      float(guidance), float(cx), float(cv), _dt(sample), _stream(), _p(coef_dev))
     _check(rc, "im360_cfg_ddim_update")
     return out
+
+
+# ------------------------------------------------------------------------------------------ tuning knobs
+KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5}
+
+
+def tuning_set(name, value):
+    """A/B switches of the launchers (tools/bench_kernels.py); none of them changes results.  Defaults are the
+    measured best, see DESIGN.md section 3b'."""
+    _check(lib().im360_tuning_set(KNOBS[name], int(value)), "im360_tuning_set")
 
 
 # ------------------------------------------------------------------------------------------ profiling

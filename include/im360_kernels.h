@@ -117,6 +117,12 @@ int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, vo
 int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
                        int64_t M, int64_t K, int64_t I, int dtype, void* stream);
 
+/* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 allow the 256x320 conv tile,
+ * 2 force 32-channel K steps, 3 scalar temporal attention, 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring
+ * kernel (asm LDS-DMA), 2 the same with the LDS-DMA builtin).  Defaults are the measured best; the IM360_* environment
+ * variables seed them at load time.  None of them changes results. */
+int im360_tuning_set(int knob, int value);
+
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
  * 3 gn_stats, 4 gn_apply, 5 layernorm/geglu/elementwise, 6 conv kernel used as a token-major linear).
  * collect() synchronises on the recorded events. */
