@@ -35,6 +35,7 @@ struct ConvParams {
     long M;             // N * Hout * Wout
     int tiles_n;        // ceil(Cout / 128)
     long nblocks;
+    int dbg;            // ablation switches of the ring kernel (tools/ab_ring.py --ablate): 1 no LDS-DMA in the K loop, 2 no MFMA, 4 no fragment reads, 8 no epilogue
 };
 
 
@@ -438,6 +439,11 @@ __device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst
                  : "memory");
 }
 
+// keep a value alive without code (ablation switches of the ring kernel; a __device__ helper because the host pass of
+// hipcc silently drops a __global__ body whose inline asm it cannot type for x86)
+__device__ __forceinline__ void keep_alive(u32x4 v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v)); }
+
 // ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
 // The kernel above keeps two LDS stages of 64 channels and drains the LDS-DMA queue at every step (one barrier per step,
 // vmcnt(0) in front of it): with one workgroup per CU a step lasts as long as its stage takes to arrive (2.7 us measured
@@ -450,7 +456,7 @@ __device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst
 //     slots 2 / 3), so the operand stream keeps flowing while accumulators are converted and stored.
 // Accumulation order over K is the same as in the kernel above (16 channels per MFMA, ascending), so results are
 // bit-identical.
-template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA>
+template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
     constexpr int BM = 256, BN = WN * TN * 32, BK = 32;
@@ -553,20 +559,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                                              (__attribute__((address_space(3))) void*)(lds + off), 16, 0, 0);
         }
     };
-    auto issue = [&](int slot) {
+    // one phase = LDA + LDB (+1 for waves 0..3 when B_TAIL) LDS-DMA instructions per wave ("pieces"), then the pointer bumps
+    constexpr int NPIECE = LDA + LDB + (B_TAIL ? 1 : 0);
+    auto issue_piece = [&](int slot, auto ic) {
+        constexpr int i = decltype(ic)::value;
         const int abase = slot * SLOT + wid_s * 1024;
         const int bbase = abase + TILE_A;
-#pragma unroll
-        for (int i = 0; i < LDA; ++i) {
+        if constexpr (i < LDA) {
             dma(aptr[i], abase + i * (NT * 16));
             aptr[i] += ((amask >> i) & 1u) ? BK : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < LDB; ++i) dma(bptr + i * bstride, bbase + i * (NT * 16));
-        if constexpr (B_TAIL) {
+        } else if constexpr (i < LDA + LDB) {
+            dma(bptr + (i - LDA) * bstride, bbase + (i - LDA) * (NT * 16));
+        } else {
             // rows 256 .. 319 of the weight tile: one more KiB for each of the first four waves
             if (wid_s < NT / 128) dma(bptr + LDB * bstride, bbase + LDB * (NT * 16));
         }
+    };
+    auto issue_advance = [&]() {
         bptr += BK;
         if constexpr (!LINEAR) {
             if (++kk_p == ksteps_per_tap) {
@@ -574,6 +583,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 if (++tap_p < p.ntaps) set_tap(tap_p);
             }
         }
+    };
+    auto issue = [&](int slot) {
+        static_for<NPIECE>([&](auto ic) { issue_piece(slot, ic); });
+        issue_advance();
     };
     // counted wait: at most `k` (0, 1, 2) of this wave's most recently requested phases may still be in flight.  The
     // count is an immediate, the per-phase number of LDS-DMA instructions differs between the wave halves (B_TAIL).
@@ -617,19 +630,119 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+        if constexpr (MODE == 1) {
+            // Two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD) run the phases ONE BARRIER INTERVAL APART:
+            // a phase is split into a read interval R (request phase + 3, fetch all 14 fragments of this phase, counted
+            // wait for the next phase's LDS-DMA) and a compute interval C (20 MFMAs from registers) with a barrier after
+            // each; while one group is in C the other is in R, so every SIMD always has one wave feeding the matrix pipe
+            // while the other hides its LDS latency and its barrier skew.  Hazards across the groups: the leading group's
+            // interval j + 1 runs beside the trailing group's interval j, and R(p + 1) / C(p) never touch the same LDS (C is
+            // register-only; R(p) requests into the slot last read in R(p - 1), one barrier earlier for both groups).
+            const int grp = wid_s >> 2;
+            wait_inflight(nph > 2 ? 1 : 0);               // phase 0 (and whatever the previous epilogue left in the queue)
+            asm volatile("s_barrier" ::: "memory");
+            if (grp) asm volatile("s_barrier" ::: "memory");          // the trailing group skips one interval
+            for (int ph = 0; ph < nph; ++ph) {
+                if (ph + 3 < nph) issue((ph + 3) & (NSLOT - 1));
+                const char* at = lds + (ph & (NSLOT - 1)) * SLOT;
+                u32x4 xf[KC][TM], wf[KC][TN];
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(at + xrow + koff[kc] + b * (32 * ROWB));
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(at + wrow + koff[kc] + a * (32 * ROWB));
+                }
+                // phase ph + 1 has to be in LDS (for every wave) one barrier before anybody reads it
+                if (ph + 1 < nph) {
+                    const int last = ph + 3 < nph - 1 ? ph + 3 : nph - 1;
+                    wait_inflight(last - (ph + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b)
+                            acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+            }
+            if (!grp) asm volatile("s_barrier" ::: "memory");         // the leading group waits for the trailing one: aligned again
+        } else if constexpr (MODE == 2) {
+            // The LDS-DMA path of a CU moves ~21 B/clk: a wave that issues its 4-5 KiB of a phase back to back sits in
+            // the issue queue for most of a phase while its MFMAs wait behind it (ablation: DMA-only and MFMA-only loop
+            // times ADD UP when every wave requests right after the barrier).  Here every piece is issued between two
+            // groups of MFMAs, so the matrix pipe has work queued while a piece waits for the memory pipeline.
+            for (int ph = 0; ph < nph; ++ph) {
+                const int rem = nph - 1 - ph;
+                wait_inflight(ph == 0 ? (rem >= 2 ? 1 : 0) : (rem >= 2 ? 2 : rem));
+                asm volatile("s_barrier" ::: "memory");      // phase ph landed for every wave; slot (ph + 3) & 3 is free again
+                const bool req = ph + 3 < nph;
+                const int rslot = (ph + 3) & (NSLOT - 1);
+                const char* at = lds + (ph & (NSLOT - 1)) * SLOT;
+                constexpr int EARLY = TN >= 4 ? TN - 2 : TN;
+                u32x4 xf[KC][TM], wf[KC][TN];
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[0][b] = *(const u32x4*)(at + xrow + koff[0] + b * (32 * ROWB));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf[0][a] = *(const u32x4*)(at + wrow + koff[0] + a * (32 * ROWB));
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[1][b] = *(const u32x4*)(at + xrow + koff[1] + b * (32 * ROWB));
+#pragma unroll
+                for (int a = 0; a < EARLY; ++a) wf[1][a] = *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
+                __builtin_amdgcn_sched_barrier(0);
+                // piece 0 goes out while the fragment reads are in flight
+                if (req) issue_piece(rslot, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<KC * TN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, kc = j / TN, a = j % TN;
+                    if constexpr (kc == 1 && a == 0 && EARLY < TN) {
+#pragma unroll
+                        for (int a2 = EARLY; a2 < TN; ++a2) wf[1][a2] = *(const u32x4*)(at + wrow + koff[1] + a2 * (32 * ROWB));
+                    }
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                    // pieces 1 .. NPIECE-1 after MFMA pairs 1, 3, 5, 7 of the ten
+                    constexpr int piece = (j % 2 == 1) ? (j / 2 + 1) : -1;
+                    if constexpr (piece >= 1 && piece < NPIECE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (req) issue_piece(rslot, std::integral_constant<int, piece>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if (req) issue_advance();
+            }
+        } else {
         for (int ph = 0; ph < nph; ++ph) {
             // phase 0 also waits for whatever the previous tile's epilogue left in the queue (its stores sit between
             // the prefetched phases 0 / 1 and phase 2)
             const int rem = nph - 1 - ph;
             wait_inflight(ph == 0 ? (rem >= 2 ? 1 : 0) : (rem >= 2 ? 2 : rem));
             asm volatile("s_barrier" ::: "memory");      // phase ph landed for every wave; slot (ph + 3) & 3 is free again
-            if (ph + 3 < nph) issue((ph + 3) & (NSLOT - 1));
+            if (ph + 3 < nph && !(p.dbg & 1)) issue((ph + 3) & (NSLOT - 1));
             const char* at = lds + (ph & (NSLOT - 1)) * SLOT;
             // fragment reads of the second 16-channel chunk are issued behind the first chunk's (its last weight
             // fragments behind the first MFMAs), which caps the live fragment registers at 44 of the 256
             static_assert(KC == 2, "two chunks per phase");
             constexpr int EARLY = TN >= 4 ? TN - 2 : TN;
             u32x4 xf[KC][TM], wf[KC][TN];
+            if (p.dbg & 4) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xf[kc][b] = u32x4{(uint32_t)ph, 1u, 2u, 3u};
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf[kc][a] = u32x4{(uint32_t)a, 1u, (uint32_t)ph, 3u};
+                }
+            } else {
 #pragma unroll
             for (int b = 0; b < TM; ++b) xf[0][b] = *(const u32x4*)(at + xrow + koff[0] + b * (32 * ROWB));
 #pragma unroll
@@ -638,7 +751,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
             for (int b = 0; b < TM; ++b) xf[1][b] = *(const u32x4*)(at + xrow + koff[1] + b * (32 * ROWB));
 #pragma unroll
             for (int a = 0; a < EARLY; ++a) wf[1][a] = *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if (p.dbg & 2) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) keep_alive(xf[kc][b]);
+#pragma unroll
+                    for (int a = 0; a < EARLY; ++a) keep_alive(wf[kc][a]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -646,7 +770,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                     acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[0][a]), __builtin_bit_cast(uint4, xf[0][b]), acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = EARLY; a < TN; ++a) wf[1][a] = *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
+            for (int a = EARLY; a < TN; ++a) wf[1][a] = (p.dbg & 4) ? u32x4{1u, 2u, 3u, 4u} : *(const u32x4*)(at + wrow + koff[1] + a * (32 * ROWB));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -654,6 +778,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[1][a]), __builtin_bit_cast(uint4, xf[1][b]), acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         asm volatile("s_barrier" ::: "memory");          // every wave is done reading operand slots
         const long next = tile + tile_step;
@@ -666,6 +791,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
         int lane_e = lane, wid_e = wid_s;
         asm volatile("" : "+v"(lane_e), "+s"(wid_e));
+        if (p.dbg & 8) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
+        } else
         tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e);
         if (next >= ntiles) break;
         tile = next;
@@ -682,8 +813,8 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         return IM360_ERR_ARG;
     }
     const int bk_env = knob(KNOB_CONV_BK);       // tuning override
-    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI == 0;      // the 8-wave tiles are BK = 64 only
-    if ((p.Cin % 64 == 0 && bk_env != 32) || !has_bk32) {
+    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI != 1;      // the 8-wave tiles are BK = 64 only
+    if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN == 5)) || !has_bk32) {      // (the 128 x 320 tile exists for two workgroups per CU: 32-channel stages)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -703,10 +834,15 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n >= 8 ? n / 8 * 8 : 8;
     }();
+    p.dbg = knob(KNOB_CONV_DBG);
     const long want = (p.nblocks + 7) / 8 * 8;
     const unsigned grid = (unsigned)(want < ncu ? want : ncu);
-    if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false>), dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true>), dim3(grid), dim3(512), 0, stream, p);
+    // variant (knob conv_ring): 1 = asm LDS-DMA, pieces interleaved with the MFMAs (default); 2 = builtin LDS-DMA, plain ring;
+    // 3 = asm LDS-DMA, plain ring; 4 = asm LDS-DMA, staggered wave groups
+    if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false, 0>), dim3(grid), dim3(512), 0, stream, p);
+    else if (variant == 3) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 0>), dim3(grid), dim3(512), 0, stream, p);
+    else if (variant == 4) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 1>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
@@ -718,7 +854,11 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
     if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
         const bool linear = p.ntaps == 1 && p.Hin == 1 && p.Win == 1 && !p.temb;       // EPI 2 has no temb add
-        if (ring_env) return linear ? launch_ring_t<T, 5, 2, true>(p, stream, ring_env) : launch_ring_t<T, 5, 0, false>(p, stream, ring_env);
+        if (big_env == 2) return linear ? launch_conv_t<T, 2, 2, 2, 5, 2>(p, stream) : launch_conv_t<T, 2, 2, 2, 5>(p, stream);   // A/B: 128 x 320, 2 workgroups per CU
+        // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
+        // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
+        if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env);
+        if (ring_env >= 5) return launch_ring_t<T, 5, 0, false>(p, stream, 1);
         if (linear) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
         return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
     }
@@ -797,8 +937,9 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
-        if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, knob(KNOB_CONV_RING));
-        if (dtype == 1) return launch_ring_t<_Float16, 4, 1, true>(p, s, knob(KNOB_CONV_RING));
+        const int v = knob(KNOB_CONV_RING) >= 5 ? 1 : knob(KNOB_CONV_RING);
+        if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);
+        if (dtype == 1) return launch_ring_t<_Float16, 4, 1, true>(p, s, v);
     }
     if (dtype == 0) return launch_conv_t<__bf16, 4, 2, 2, 4, 1>(p, s);
     if (dtype == 1) return launch_conv_t<_Float16, 4, 2, 2, 4, 1>(p, s);

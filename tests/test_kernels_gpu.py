@@ -236,6 +236,42 @@ def test_linear_residual_through_gemm_kernel(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_pipeline_variants_are_bit_identical(dt):
+    """The persistent ring kernel (knob conv_ring 1: interleaved LDS-DMA, 3: plain ring, 4: staggered wave groups, 5: also
+    for convolutions) accumulates in the same order as the two-stage kernel (0): identical bits, on a ragged token count,
+    a GEGLU projection and a 3x3 convolution with temb + residual; and the result matches the fp32 reference."""
+    g = torch.Generator().manual_seed(60)
+    M, Kd, N = 131073, 128, 320
+    x = torch.randn(M, 1, 1, Kd, generator=g).to(dt).cuda()
+    w = (torch.randn(N, Kd, 1, 1, generator=g) * Kd ** -0.5).to(dt).cuda()
+    b, r = torch.randn(N, generator=g).to(dt).cuda(), torch.randn(M, 1, 1, N, generator=g).to(dt).cuda()
+    wp = K.pack_conv_weight(w)
+    gx = torch.randn(65536, 64, generator=g).to(dt).cuda()
+    gw, gb = (torch.randn(512, 64, generator=g) * 0.125).to(dt).cuda(), torch.randn(512, generator=g).to(dt).cuda()
+    gwp, gbp = K.pack_geglu(gw, gb)
+    cx = torch.randn(145, 30, 31, 64, generator=g).to(dt).cuda()
+    cw = (torch.randn(320, 64, 3, 3, generator=g) * 576 ** -0.5).to(dt).cuda()
+    cwp = K.pack_conv_weight(cw)
+    temb, cres = torch.randn(29, 320, generator=g).to(dt).cuda(), torch.randn(145, 30, 31, 320, generator=g).to(dt).cuda()
+    outs = {}
+    try:
+        for v in (0, 1, 3, 4, 5):
+            K.tuning_set("conv_ring", v)
+            outs[v] = (K.conv2d(x, wp, N, bias=b, res=r), K.linear_geglu(gx, gwp, gbp, 256),
+                       K.conv2d(cx, cwp, 320, bias=b, temb=temb, imgs_per_temb=5, res=cres))
+    finally:
+        K.tuning_set("conv_ring", 1)
+    for v in (1, 3, 4, 5):
+        for a, ref in zip(outs[v], outs[0]):
+            assert torch.equal(a, ref), v
+    lin_ref = (x[:, 0, 0].float() @ w[:, :, 0, 0].float().t() + b.float()).to(dt).float() + r[:, 0, 0].float()
+    assert rel(outs[1][0][:, 0, 0], lin_ref) < TOL[dt]
+    conv_ref = (F.conv2d(cx.float().permute(0, 3, 1, 2), cw.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+                + temb.float().repeat_interleave(5, 0)[:, None, None, :]).to(dt).float() + cres.float()
+    assert rel(outs[5][2], conv_ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_linear_geglu_fused(dt):
     """GEGLU projection + activation in one GEMM launch (interleaved value / gate weight rows) vs Linear -> chunk ->
     a * gelu(gate) in fp32, including a ragged last token tile; and the module-level switch in layers.GEGLU."""

@@ -15,7 +15,7 @@ from imagine360_amd import kernels as K  # noqa: E402
 
 DT = torch.bfloat16
 DEV = "cuda"
-VARIANTS = [0, 1, 2]
+VARIANTS = [0, 1, -2]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles (two workgroups per CU)
 
 
 def rn(*s, scale=1.0):
@@ -38,11 +38,13 @@ def timeit(fn, iters):
 def run_variants(name, fn, flops, bytes_, iters, check):
     outs, times = [], []
     for v in VARIANTS:
-        K.tuning_set("conv_ring", v)
+        K.tuning_set("conv_ring", max(v, 0))
+        K.tuning_set("conv_big", 2 if v == -2 else 1)
         if check:
             outs.append(fn().clone())
         times.append(timeit(fn, iters))
     K.tuning_set("conv_ring", 1)
+    K.tuning_set("conv_big", 1)
     same = ""
     if check:
         same = " identical" if all(torch.equal(outs[0], o) for o in outs[1:]) else " MISMATCH " + " ".join(
@@ -53,7 +55,35 @@ def run_variants(name, fn, flops, bytes_, iters, check):
           + f" | best {flops / best / 1e9:6.0f} TF/s {bytes_ / best / 1e9:5.2f} TB/s{same}", flush=True)
 
 
+def ablate(iters):
+    """Where the time of the ring kernel (variant 3: no stagger) goes: switch off parts of it (results are garbage)."""
+    torch.manual_seed(0)
+    cases = []
+    x, w = rn(655360, 1, 1, 320), K.pack_conv_weight(rn(320, 320, 1, 1, scale=320 ** -0.5))
+    b, r = rn(320), rn(655360, 1, 1, 320)
+    cases.append(("lin L0 out 320>320 +b+res", lambda: K.conv2d(x, w, 320, bias=b, res=r)))
+    x2, w2 = rn(163840, 1, 1, 2560), K.pack_conv_weight(rn(640, 2560, 1, 1, scale=2560 ** -0.5))
+    cases.append(("lin L1 ffout 2560>640", lambda: K.conv2d(x2, w2, 640)))
+    x3, w3 = rn(640, 32, 32, 320), K.pack_conv_weight(rn(320, 320, 3, 3, scale=2880 ** -0.5))
+    cases.append(("conv pers L0 320>320", lambda: K.conv2d(x3, w3, 320, bias=b)))
+    x4, w4 = rn(640, 16, 16, 640), K.pack_conv_weight(rn(640, 640, 3, 3, scale=5760 ** -0.5))
+    cases.append(("conv pers L1 640>640", lambda: K.conv2d(x4, w4, 640)))
+    K.tuning_set("conv_ring", 3)
+    for name, fn in cases:
+        row = []
+        for dbg, lab in [(0, "full"), (1, "noDMA"), (2, "noMFMA"), (4, "noREAD"), (8, "noEPI"), (5, "noDMA+noREAD"),
+                         (3, "noDMA+noMFMA"), (6, "noMFMA+noREAD"), (7, "barriers only"), (15, "nothing")]:
+            K.tuning_set("conv_dbg", dbg)
+            row.append(f"{lab}={timeit(fn, iters):.3f}")
+        K.tuning_set("conv_dbg", 0)
+        print(f"{name:28s} " + " ".join(row), flush=True)
+    K.tuning_set("conv_ring", 1)
+
+
 def main():
+    if "--ablate" in sys.argv:
+        torch.set_grad_enabled(False)
+        return ablate(10)
     iters = 10
     if "--iters" in sys.argv:
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
