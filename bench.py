@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """Benchmark of the dual-branch denoising hot path (BASELINE.json metric: denoising steps/sec).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: re-executes itself under
+                                                              torch.distributed.run, one rank per GPU over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one CFG-batched MultiViewBaseModel.forward (both UNets + 7 WarpAttn) + CFG combine + the two
-DDIM updates, on synthetic inputs already resident in HBM.  N > 1 = sample-parallel
-(one independent sample per GPU, weights replicated, BASELINE config 3): weak scaling, no per-step
-collective, one all-gather of the final panorama latents at the latent boundary inside the timed region.
+DDIM updates, on synthetic inputs already resident in HBM.
+
+  --parallelism samples (default, BASELINE config 3): one independent sample per GPU, weights replicated, no per-step
+      collective, one all-gather of the final panorama latents inside the timed region.  Weak scaling.
+  --parallelism frames (BASELINE config 4, and 5 at N <= frames): ONE sample, contiguous frame chunks per GPU; every
+      motion-module attention exchanges tokens with one all-to-all each way (imagine360_amd.dist.FrameShard), the
+      latents are all-gathered along the frame axis at the end.  Strong scaling.
+  --parallelism cfgxframes (BASELINE config 5 on 8 GPUs): the two CFG halves on two rank groups, frames sharded inside
+      each group; per step the halves exchange their predictions pairwise for the CFG combine.  Strong scaling.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,30 +34,24 @@ from imagine360_amd import configs, flops, kernels, synthetic  # noqa: E402
 from imagine360_amd.scheduler import DDIMScheduler  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0           # HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy kernel reaches)
 WORKLOADS = {
     "cfg2": dict(frames=16, pano_hw=(64, 128), pers_hw=(32, 32), pers_px=256,
                  desc="BASELINE cfg2: 16-frame 512x1024 equirect (pano latent 4x16x64x128 + 20 views 4x16x32x32), "
                       "CFG batch 2, full-width random-init UNets, DDIM step"),
     "cfg1": dict(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), pers_px=128,
                  desc="BASELINE cfg1 shapes: 8-frame 256x512 equirect, CFG batch 2"),
+    "cfg4": dict(frames=48, pano_hw=(64, 128), pers_hw=(32, 32), pers_px=256,
+                 desc="BASELINE cfg4 shapes: 48-frame 512x1024 equirect, CFG batch 2 (frame-chunk sharding)"),
     "cfg5": dict(frames=16, pano_hw=(128, 256), pers_hw=(64, 64), pers_px=512,
                  desc="BASELINE cfg5 shapes: 16-frame 1024x2048 equirect, CFG batch 2"),
 }
 
 
-def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference path, fp32, all host threads) timed on a BOUNDED sample and scaled
-    to the benchmarked workload by the analytic FLOP ratio.  Sample = the three block types that carry ~95 % of a
-    step's FLOPs (ResnetBlock3D, spatial Transformer3DModel, motion module) at FULL channel width at UNet levels 0
-    (320 ch, 32x32) and 2 (1280 ch, 8x8) on 8 frames of 12 views -- full width because CPU GEMM/conv efficiency depends
-    on the channel widths, a small batch because a whole cfg2 step would take ~10 minutes of host time."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from im360_oracle import unet as OU
-    from imagine360_amd.mv_model import MultiViewBaseModel
-    from imagine360_amd.weights import filler_tensor
+def _best_threads():
+    """Thread count that maximises fp32 GEMM throughput on this host (oversubscribing a 256-thread box makes the small
+    per-frame ops of this path 3x slower)."""
     cores = os.cpu_count() or 1
-    # give the CPU its best shot: pick the thread count that maximises fp32 GEMM throughput on this host
-    # (oversubscribing a 256-thread box makes the small per-frame ops of this path 3x slower)
     best, best_t = cores, 0.0
     a, bm = torch.randn(4096, 1280), torch.randn(1280, 1280)
     for nt in sorted({min(cores, c) for c in (16, 32, 64, 128, cores)}):
@@ -61,6 +64,55 @@ def cpu_baseline(args):
         if r > best_t:
             best, best_t = nt, r
     torch.set_num_threads(best)
+    return best
+
+
+def cpu_baseline_step(mv, args):
+    """The oracle (CPU restatement of the reference path, fp32) timed on ONE FULL-WIDTH denoising step of BASELINE cfg1
+    (8 frames of 256x512: the reference's own CPU-runnable case, 31.9 TFLOP), with the GPU model's weights, on the host
+    cores of this box.  cfg2 itself would take ~8x longer; its figure is the measured cfg1 rate scaled by the analytic
+    FLOP ratio, stated separately."""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from im360_oracle import mv as OMV
+    from im360_oracle.cfg import sd21_unet_cfg
+    nthreads = _best_threads()
+    w1 = WORKLOADS["cfg1"]
+    cfg = sd21_unet_cfg(args.width_div)
+    cfg.xformers = True
+    sd = {k: v.detach().float().cpu() for k, v in mv.state_dict().items()}
+    inp = synthetic.mv_inputs(frames=w1["frames"], pano_hw=w1["pano_hw"], pers_hw=w1["pers_hw"], seed=1, sam_frames=16)
+    cams = synthetic.icosahedron_cameras(90, w1["pers_px"])
+    torch.manual_seed(0)
+    random.seed(0)
+    t0 = time.time()
+    with torch.no_grad():
+        o_pers, o_pano = OMV.mv_forward(sd, cfg, inp["latents"], inp["pano_latent"], inp["timestep"], inp["prompt_embd"],
+                                        inp["pano_prompt_embd"], cams, inp["fps_tensor_pano"], inp["fps_tensor_pers"],
+                                        inp["reference_images_clip_feat_pano"], inp["reference_images_clip_feat_pers"],
+                                        inp["relative_position_tensor"], inp["pitchs_tensor"], mask_cache={})
+    dt = time.time() - t0
+    assert torch.isfinite(o_pano).all()
+    boc = tuple(mv.unet.config.block_out_channels)
+    f1 = flops.step_flops(frames=w1["frames"], pano_hw=w1["pano_hw"], pers_hw=w1["pers_hw"], block_out_channels=boc)
+    w = WORKLOADS[args.workload]
+    fw = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], block_out_channels=boc)
+    return {"value": (1.0 / dt) * f1 / fw, "unit": "denoising steps/sec", "cores": nthreads, "kind": "port",
+            "sample": f"ONE full-width oracle step of BASELINE cfg1 (8 frames, 256x512 equirect, CFG batch 2, "
+                      f"{f1 / 1e12:.1f} TFLOP incl. the IP-adapter conditioning and mask building the GPU path hoists): "
+                      f"measured {dt:.1f} s on {nthreads} host threads = {f1 / dt / 1e12:.3f} TFLOP/s",
+            "measured_cfg1_s_per_step": dt, "measured_cfg1_steps_per_s": 1.0 / dt,
+            "extrapolation": f"value = measured cfg1 steps/s x ({f1 / 1e12:.1f} / {fw / 1e12:.1f}) analytic FLOP ratio to {args.workload}"}
+
+
+def cpu_baseline_sample(args):
+    """Bounded alternative (--cpu-baseline sample): the oracle's ResnetBlock3D + spatial transformer + motion module at
+    FULL width at UNet levels 0 and 2 on 8 frames of 12 views (~10 s), scaled by the analytic FLOP ratio."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from im360_oracle import unet as OU
+    from imagine360_amd.mv_model import MultiViewBaseModel
+    from imagine360_amd.weights import filler_tensor
+    nthreads = _best_threads()
     with torch.device("meta"):
         meta = MultiViewBaseModel(configs.build_unet(1), configs.build_unet(1)).state_dict()
     frames, ctx_n, views = 8, 141, 12
@@ -74,9 +126,9 @@ def cpu_baseline(args):
             emb = torch.randn(views, 1280, generator=g)
             ctx = torch.randn(views, ctx_n, 1024, generator=g)
             n = h * w * views
-            fl = 2 * (2.0 * c * c * 9 * n * frames)                                                  # two 3x3 convs
-            fl += frames * n * (2.0 * c * c * 2 + 2.0 * c * c * 4 + 2.0 * c * c * 2 + 2.0 * c * 8 * c + 2.0 * 4 * c * c)   # spatial GEMMs
-            fl += views * frames * ctx_n * 2.0 * 1024 * c * 2 + 4.0 * n * ctx_n * c * frames + 4.0 * n * (h * w) * c * frames     # cross K/V, cross, self
+            fl = 2 * (2.0 * c * c * 9 * n * frames)
+            fl += frames * n * (2.0 * c * c * 2 + 2.0 * c * c * 4 + 2.0 * c * c * 2 + 2.0 * c * 8 * c + 2.0 * 4 * c * c)
+            fl += views * frames * ctx_n * 2.0 * 1024 * c * 2 + 4.0 * n * ctx_n * c * frames + 4.0 * n * (h * w) * c * frames
             fl += n * frames * (2.0 * c * c * 2 + 2 * (2.0 * c * c * 4) + 2.0 * c * 8 * c + 2.0 * 4 * c * c) + 2 * 4.0 * frames * frames * c * n
             t0 = time.time()
             y = OU.resnet_block(sd, pre + res, x, emb)
@@ -90,10 +142,25 @@ def cpu_baseline(args):
     w = WORKLOADS[args.workload]
     full_tf = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"]) / 1e12
     cpu_tflops = tot_flops / tot_time / 1e12
-    return {"value": cpu_tflops / full_tf, "unit": "denoising steps/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": cpu_tflops / full_tf, "unit": "denoising steps/sec", "cores": nthreads, "kind": "port",
             "sample": "oracle ResnetBlock3D + spatial transformer + motion module, full width, fp32, 8 frames of 12 views ("
-                      + "; ".join(parts) + f") = {cpu_tflops:.3f} TFLOP/s on {torch.get_num_threads()} host threads; scaled to the "
+                      + "; ".join(parts) + f") = {cpu_tflops:.3f} TFLOP/s on {nthreads} host threads; scaled to the "
                       f"{full_tf:.1f} TF step of {args.workload} by the analytic FLOP ratio"}
+
+
+def _respawn(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run (RCCL over xGMI)."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -102,18 +169,29 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--parallelism", default="samples", choices=["samples", "frames", "cfgxframes"])
     ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--cpu-baseline", default="step", choices=["step", "sample", "none"],
+                    help="step: one full-width cfg1 oracle step on the host cores (~1 min); sample: bounded block sample (~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="hipBLASLt default heuristic instead of the shipped solution table")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_hbm_traffic.json"),
+                    help="rocprofv3 PMC summary (tools/hbm_traffic.sh) the roofline block quotes HBM traffic from")
     args = ap.parse_args()
+    if args.no_cpu_baseline:
+        args.cpu_baseline = "none"
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE {world}: the two must agree")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -121,11 +199,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     w = WORKLOADS[args.workload]
+    frames = w["frames"]
+    mode = args.parallelism if world > 1 else "samples"
     torch.set_grad_enabled(False)
     kernels.lib()
     tuned = False
@@ -133,9 +211,26 @@ def main():
         from imagine360_amd import tuning
         tuned = tuning.enable()
     mv = configs.build_mv_model(args.width_div, device=dev, dtype=dt, xformers=True)
-    inp = synthetic.mv_inputs(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=1 + rank,
-                              sam_frames=max(16, w["frames"]), dtype=dt, device=dev)
+    # samples: every rank its own sample (seed); frame modes: ONE sample, replicated conditioning, identical RNG streams
+    seed = 1 + rank if mode == "samples" else 1
+    inp = synthetic.mv_inputs(frames=frames, pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=seed,
+                              sam_frames=max(16, frames), dtype=dt, device=dev)
     cams = synthetic.icosahedron_cameras(90, w["pers_px"], device=dev)
+    shard, pair = None, None
+    if mode != "samples":
+        import random
+        from imagine360_amd.dist import FrameShard, exchange_cfg_halves, shard_mv_inputs
+        torch.manual_seed(1234)
+        random.seed(1234)
+        if mode == "frames":
+            shard = FrameShard(frames)
+        else:
+            from imagine360_amd.dist import cfg_frame_layout, cfg_half_inputs
+            my_half, shard, pair = cfg_frame_layout(frames)
+            inp = cfg_half_inputs(inp, my_half)
+            mv._ip_noise_half = (my_half, 2)
+        inp = shard_mv_inputs(inp, shard)
+        mv.set_frame_shard(shard)
     sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
     nsteps_total = 25
     sch.set_timesteps(nsteps_total)
@@ -161,6 +256,9 @@ def main():
             reference_images_clip_feat_pano=inp["reference_images_clip_feat_pano"],
             reference_images_clip_feat_pers=inp["reference_images_clip_feat_pers"],
             relative_position_tensor=inp["relative_position_tensor"], pitchs_tensor=inp["pitchs_tensor"])
+        if pair is not None:
+            # CFG combine across the two halves: each rank receives its partner's prediction of the same frames
+            pred_pano, pred_pers = exchange_cfg_halves(pred_pano, pair), exchange_cfg_halves(pred_pers, pair)
         pano_lat = sch.fused_cfg_step(pred_pano[0:1], pred_pano[1:2], guidance, ts_host[t], pano_lat)
         pers_lat = sch.fused_cfg_step(pred_pers[0:1], pred_pers[1:2], guidance, ts_host[t], pers_lat)
 
@@ -173,7 +271,7 @@ def main():
 
     prof_kinds = ["conv", "gemm", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
     graphed = None
-    if not args.no_graph:
+    if not args.no_graph and shard is None:
         # the step is ~3000 launches: capture it once (hipGraph) and replay, so the host is out of the loop
         from imagine360_amd.graph_step import GraphedDenoiseStep
         try:
@@ -188,19 +286,26 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if dist is not None:          # untimed: first use of the collective (RCCL channel setup is lazy)
-        warm = [torch.empty_like(pano_lat) for _ in range(world)]
-        dist.all_gather(warm, pano_lat if graphed is None else graphed.pano_lat)
-        del warm
+    if dist is not None:          # untimed: first use of the boundary collective (RCCL channel setup is lazy)
+        cur = pano_lat if graphed is None else graphed.pano_lat
+        if shard is not None:
+            shard.gather_frames(cur, 2)
+        else:
+            warm = [torch.empty_like(cur) for _ in range(world)]
+            dist.all_gather(warm, cur)
+            del warm
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     if graphed is not None:
         pano_lat = graphed.pano_lat
-    if dist is not None:          # latent boundary: gather every rank's panorama latent (1 MB each)
-        gathered = [torch.empty_like(pano_lat) for _ in range(world)]
-        dist.all_gather(gathered, pano_lat)
+    if dist is not None:          # latent boundary: gather every rank's panorama latent (1 MB each) / frame chunk
+        if shard is not None:
+            full_lat = shard.gather_frames(pano_lat, 2)
+        else:
+            gathered = [torch.empty_like(pano_lat) for _ in range(world)]
+            dist.all_gather(gathered, pano_lat)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -209,13 +314,15 @@ def main():
         elapsed = float(tmax.item())
     # per-kernel-class durations: the same K steps once more, issued eagerly with HIP events around every launch
     # of our kernels (a graph replay has no per-launch host hook); kernel durations do not depend on how they were launched
-    if rank == 0:
+    eager_elapsed = None
+    if rank == 0 and shard is None:
         if graphed is not None:
             pano_lat, pers_lat = graphed.pano_lat.clone(), graphed.pers_lat.clone()
 
             def step(i):                                                   # noqa: F811
                 eager_step(i)
         kernels.prof_enable(prof_kinds)
+        kernels.STATS = {}
         t1 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
@@ -225,43 +332,81 @@ def main():
     finite = bool(torch.isfinite(pano_lat.float()).all().item())
 
     if rank == 0:
-        prof = {k: kernels.prof_collect(k) for k in prof_kinds}
         boc = tuple(mv.unet.config.block_out_channels)
-        total, parts = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"],
+        total, parts = flops.step_flops(frames=frames, pano_hw=w["pano_hw"], pers_hw=w["pers_hw"],
                                         block_out_channels=boc, breakdown=True)
-        conv_flops = parts["pers conv"] + parts["pano conv"]
-        attn_flops = parts["pers self-attn"] + parts["pano self-attn"] + parts["WarpAttn attn"]
-        conv_ms, conv_n = prof["conv"]
-        attn_ms, attn_n = prof["attn"]
-        conv_tfs = conv_flops * args.steps / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        attn_tfs = attn_flops * args.steps / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
-        steps_per_s = world * args.steps / elapsed
+        samples = world if mode == "samples" else 1
+        steps_per_s = samples * args.steps / elapsed
         out = {
             "metric": "denoising steps/sec (dual-branch UNet, 16x512x1024 latent)",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if mode == "samples" else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tuned_gemm_table": tuned,
             "launch": "eager" if graphed is None else "hipGraph replay (one captured step)",
-            "eager_ms_per_step": 1e3 * eager_elapsed / args.steps,
-            "config": {"workload": w["desc"], "parallelism": f"sample-parallel x{world}" if world > 1 else "single GPU",
+            "config": {"workload": w["desc"],
+                       "parallelism": {"samples": f"sample-parallel x{world}" if world > 1 else "single GPU",
+                                       "frames": f"frame-chunk sharding x{world} ({frames // max(world, 1)} frames per GPU)",
+                                       "cfgxframes": f"CFG halves x frame chunks (2 x {world // 2})"}[mode],
                        "width_div": args.width_div, "ddim_steps_schedule": nsteps_total, "guidance": guidance,
                        "tflop_per_step": total / 1e12, "outputs_finite": finite},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (GroupNorm+SiLU'd 3x3/1x1 conv, implicit GEMM)",
-                         "achieved": conv_tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tfs / MFMA_PEAK_TFLOPS, "traffic": None,
-                         "launches_per_step": conv_n / max(args.steps, 1), "avg_launch_ms": conv_ms / max(conv_n, 1),
-                         "algorithmic_tflop_per_step": conv_flops / 1e12},
-            "kernels": {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items()},
-            "attention": {"achieved": attn_tfs, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tfs / MFMA_PEAK_TFLOPS,
-                          "algorithmic_tflop_per_step": attn_flops / 1e12,
-                          "note": "self-attention + WarpAttn QK^T/PV flops over all attn_fwd launches (cross-attention launches "
-                                  "included in the time, their small flops not counted)"},
-            "whole_step_tflops": total / 1e12 * steps_per_s / world,
+            "whole_step_tflops": total / 1e12 * steps_per_s / world,          # per GPU
             "whole_step_frac_of_mfma_peak": total / 1e12 * steps_per_s / world / MFMA_PEAK_TFLOPS,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+        if eager_elapsed is not None:
+            prof = {k: kernels.prof_collect(k) for k in prof_kinds}
+            stats, kernels.STATS = kernels.STATS, None
+            out["eager_ms_per_step"] = 1e3 * eager_elapsed / args.steps
+            out["profile_source"] = ("HIP events (on the launch stream) around every launch of our kernels during a separate eager pass of "
+                                     "the same K steps, after the timed region; algorithmic flops / bytes counted per launch")
+            classes = {}
+            for kname, (ms, n) in prof.items():
+                fl, by, _ = stats.get(kname, [0.0, 0.0, 0])
+                t = ms * 1e-3
+                t_mfma, t_hbm = fl / (MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+                c = {"ms_per_step": ms / args.steps, "launches_per_step": n / args.steps,
+                     "algorithmic_tflop_per_step": fl / args.steps / 1e12, "algorithmic_gb_per_step": by / args.steps / 1e9}
+                if t > 0:
+                    c.update({"tflops": fl / t / 1e12, "frac_of_mfma_peak": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                              "gbs": by / t / 1e9, "frac_of_hbm_peak": by / t / 1e9 / HBM_PEAK_GBS,
+                              "bound": "mfma" if t_mfma >= t_hbm else "hbm", "roofline_frac": max(t_mfma, t_hbm) / t})
+                classes[kname] = c
+            out["kernels"] = classes
+            # the roofline block: the class of our kernels that takes the most time per step (conv_igemm / conv_ring as
+            # convolution, or the same kernels as token-major GEMMs)
+            dom = max(("conv", "gemm"), key=lambda k: classes[k]["ms_per_step"])
+            c = classes[dom]
+            names = {"conv": "conv_igemm_kernel (GroupNorm+SiLU'd 3x3/1x1 convolutions, implicit GEMM)",
+                     "gemm": "conv_ring_kernel / conv_igemm_kernel as token-major GEMMs (Linear + bias/residual, fused GEGLU)"}
+            traffic, tnote = None, "no PMC summary found"
+            if os.path.isfile(args.traffic_json):
+                try:
+                    tj = json.load(open(args.traffic_json))
+                    rows = [v for v in tj.get(dom, {}).values() if isinstance(v, dict) and "traffic_bytes" in v]
+                    if rows:
+                        traffic = sum(r["traffic_bytes"] for r in rows) / len(rows)
+                        tnote = (f"mean measured HBM-side bytes per launch over the {len(rows)} {dom} shapes of "
+                                 f"{os.path.relpath(args.traffic_json, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                 "gfx950 x2 fetch correction); algorithmic bytes of the same shapes: "
+                                 f"{sum(r.get('algorithmic_bytes', 0.0) for r in rows) / len(rows):.3e}")
+                except (ValueError, OSError) as e:
+                    tnote = f"unreadable PMC summary: {e}"
+            out["roofline"] = {"bound": "mfma", "kernel": names[dom], "class": dom,
+                               "achieved": c.get("tflops", 0.0), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": c.get("frac_of_mfma_peak", 0.0), "traffic": traffic, "traffic_note": tnote,
+                               "launches_per_step": c["launches_per_step"],
+                               "avg_launch_ms": c["ms_per_step"] / max(c["launches_per_step"], 1e-9),
+                               "algorithmic_tflop_per_step": c["algorithmic_tflop_per_step"],
+                               "hbm_view": {"achieved_gbs": c.get("gbs", 0.0), "frac_of_hbm_peak": c.get("frac_of_hbm_peak", 0.0),
+                                            "class_bound": c.get("bound"), "roofline_frac": c.get("roofline_frac")}}
+            a = classes["attn"]
+            out["attention"] = {"achieved": a.get("tflops", 0.0), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": a.get("frac_of_mfma_peak", 0.0),
+                                "algorithmic_tflop_per_step": a["algorithmic_tflop_per_step"],
+                                "note": "QK^T + PV flops of every attn_fwd launch (self, text + IP cross, WarpAttn) over their summed time"}
+        if world == 1 and args.cpu_baseline != "none":
+            out["cpu_baseline"] = cpu_baseline_step(mv, args) if args.cpu_baseline == "step" else cpu_baseline_sample(args)
             out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

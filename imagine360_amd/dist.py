@@ -50,6 +50,55 @@ def shard_samples(items, rank=None, world=None):
     return list(items)[rank::world]
 
 
+FRAME_AXIS = {"latents": 3, "pano_latent": 2}       # frame axis of the model inputs that are per-frame
+
+
+def shard_mv_inputs(inputs, shard):
+    """Frame-chunk view of the keyword tensors of ``MultiViewBaseModel.forward``: the noisy / masked latents are cut to
+    this rank's frames; everything else (text, SAM features of ALL frames, relative positions, pitches, fps) is
+    step-invariant conditioning that every rank holds in full -- the IP-adapter's temporal projection and the
+    per-frame position tokens are functions of the whole clip (src/models/MVGenModel.py:155-222)."""
+    out = dict(inputs)
+    for k, ax in FRAME_AXIS.items():
+        out[k] = shard.take(inputs[k], ax).contiguous()
+    return out
+
+
+def cfg_half_inputs(inputs, half):
+    """BASELINE config 5 splits the two classifier-free-guidance halves over two rank groups: keep the unconditional
+    (half 0) or the text-conditioned (half 1) half of every CFG-batched model input.  The halves never interact inside
+    the model; only the CFG combine needs both (``exchange_cfg_halves``)."""
+    m = inputs["latents"].shape[1]
+    out = dict(inputs)
+    for k, v in inputs.items():
+        if k != "timestep" and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] in (2, 2 * m):
+            out[k] = v.chunk(2)[half]                 # a view: broadcast (stride-0) feature tensors stay shared
+    return out
+
+
+def exchange_cfg_halves(pred, pair_group):
+    """Both halves' predictions of the same frames, [uncond, text] along dim 0, on both ranks of ``pair_group``
+    (= [rank of half 0, rank of half 1]): one small all-gather per branch and step."""
+    parts = [torch.empty_like(pred) for _ in range(2)]
+    dist.all_gather(parts, pred.contiguous(), group=pair_group)
+    return torch.cat(parts)
+
+
+def cfg_frame_layout(frames, world=None, rank=None):
+    """Rank layout of the CFG x frames decomposition: ranks [0, world/2) take the unconditional half, the rest the text
+    half; inside a half the frames are sharded.  Returns (half index, FrameShard of the half, pair group).  Every rank
+    must call this (it creates process groups collectively)."""
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    if world % 2:
+        raise ValueError("the CFG x frames layout needs an even number of ranks")
+    half = world // 2
+    groups = [dist.new_group(list(range(h * half, (h + 1) * half))) for h in range(2)]
+    pairs = [dist.new_group([r, r + half]) for r in range(half)]
+    my_half = rank // half
+    return my_half, FrameShard(frames, group=groups[my_half], rank=rank % half, world=half), pairs[rank % half]
+
+
 class FrameShard:
     """Contiguous frame chunks across the ranks of ``group`` (frames % world == 0)."""
 
@@ -69,6 +118,8 @@ class FrameShard:
 
     def gather_frames(self, x, dim):
         """All-gather the frame chunks back along ``dim`` (latent boundary)."""
+        if self.world == 1:
+            return x
         parts = [torch.empty_like(x) for _ in range(self.world)]
         dist.all_gather(parts, x.contiguous(), group=self.group)
         return torch.cat(parts, dim=dim)
@@ -77,6 +128,8 @@ class FrameShard:
     def frames_to_pixels(self, x):
         b, fl, p, c = x.shape
         w = self.world
+        if w == 1:
+            return x
         pp = -(-p // w)                                   # pixels per rank, last rank zero-padded
         if pp * w != p:
             x = torch.nn.functional.pad(x, (0, 0, 0, pp * w - p))
@@ -88,6 +141,8 @@ class FrameShard:
     def pixels_to_frames(self, y, pixels):
         b, f, pp, c = y.shape
         w, fl = self.world, self.local
+        if w == 1:
+            return y
         send = y.reshape(b, w, fl, pp, c).permute(1, 0, 2, 3, 4).contiguous()           # [w, b, fl, pp, c]
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)

@@ -37,6 +37,18 @@ _SIGNATURES = {
 PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
 
 
+# Algorithmic work of the launches, by class (bench.py's roofline legs): None = off, else {class: [flops, bytes, launches]}
+STATS = None
+
+
+def _count(kind, flops, nbytes):
+    if STATS is not None:
+        s = STATS.setdefault(kind, [0.0, 0.0, 0])
+        s[0] += flops
+        s[1] += nbytes
+        s[2] += 1
+
+
 def exported_symbols():
     return sorted(_SIGNATURES)
 
@@ -109,6 +121,8 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
                               out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0, kv_group,
                               float(scale), float(out_scale), int(accumulate), _dt(q), _stream(), _p(bias_alt), _p(bias_sel))
     _check(rc, "im360_attn_fwd")
+    _count("attn", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
+           + (0 if bias is None else bias.element_size() * Nq * Nk))
     return out
 
 
@@ -126,6 +140,7 @@ def temporal_attention(qkv, B, F, P, heads):
                                        P * rs, rs, F * P * rs, P * C, C, F * P * C,
                                        float(d ** -0.5), _dt(qkv), _stream())
     _check(rc, "im360_temporal_attn_fwd")
+    _count("temporal", 4.0 * B * P * heads * F * F * d, qkv.element_size() * 4 * B * F * P * C)
     return out
 
 
@@ -143,6 +158,7 @@ def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
     rc = lib().im360_groupnorm_stats(_p(x), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
                                      N, H, W, C, groups, pad, float(eps), _dt(x), _stream())
     _check(rc, "im360_groupnorm_stats")
+    _count("gn_stats", 0.0, x.element_size() * x.numel())
     return scale, shift
 
 
@@ -155,6 +171,7 @@ def group_norm_apply(x, scale, shift, silu, pad=0):
     rc = lib().im360_groupnorm_apply(_p(x), _p(scale), _p(shift), _p(y), N, H, W, C, pad, int(bool(silu)),
                                      _dt(x), _stream())
     _check(rc, "im360_groupnorm_apply")
+    _count("gn_apply", 0.0, x.element_size() * (x.numel() + y.numel()))
     return y
 
 
@@ -198,6 +215,11 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
                               N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
                               imgs_per_temb, _dt(x), _stream())
     _check(rc, "im360_conv_fwd")
+    if STATS is not None:
+        es = x.element_size()
+        linear = taps == 1 and Hin == 1 and Win == 1
+        _count("gemm" if linear else "conv", 2.0 * N * hout * wout * Cin * cout * taps,
+               es * (x.numel() + cout * taps * Cin + y.numel() * (2 if res is not None else 1)))
     return y
 
 
@@ -216,6 +238,7 @@ def layer_norm(x, gamma, beta, eps=1e-5, pre=None, post=None, post_div=1):
                                pre.shape[0] if pre is not None else 1, post_div,
                                post.shape[0] if post is not None else 1, float(eps), _dt(x), _stream())
     _check(rc, "im360_layernorm")
+    _count("misc", 0.0, 2 * x.element_size() * x.numel())
     return y
 
 
@@ -227,6 +250,7 @@ def geglu(h):
     out = torch.empty(h.shape[:-1] + (I,), dtype=h.dtype, device=h.device)
     rc = lib().im360_geglu(_p(h), _p(out), h.numel() // (2 * I), I, _dt(h), _stream())
     _check(rc, "im360_geglu")
+    _count("misc", 0.0, h.element_size() * (h.numel() + out.numel()))
     return out
 
 
@@ -262,6 +286,7 @@ def linear_geglu(x, w_packed, bias_packed, inner):
     y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
     rc = lib().im360_linear_geglu(_p(x), _p(w_packed), _p(bias_packed), _p(y), m, k, inner, _dt(x), _stream())
     _check(rc, "im360_linear_geglu")
+    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()))
     return y
 
 

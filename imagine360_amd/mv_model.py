@@ -138,6 +138,7 @@ class MultiViewBaseModel(nn.Module):
         self._rig_cache = {}
         self._coins_dev = None          # int32[8] on the device: the 7 WarpAttn coins of the current step
         self.coins_preloaded = False    # True while a captured graph replays: the driver draws + uploads the coins
+        self._ip_noise_half = None      # (half index, 2) when this rank runs one CFG half (BASELINE config 5 layout)
 
     def draw_coins(self, device):
         """The reference draws ``random.random() < 0.4`` once per WarpAttn call (src/utils/utils.py:15), 7 per step in
@@ -174,6 +175,16 @@ class MultiViewBaseModel(nn.Module):
                 mod.frame_shard = shard
 
     def _ip_noise(self, like):
+        half = self._ip_noise_half
+        if half is not None:
+            # this rank runs ONE of the CFG halves (dist.cfg_half_inputs): draw the whole CFG batch's noise, keep our rows,
+            # so the two rank groups together reproduce the CFG-batched run's stream
+            idx, n = half
+            full = torch.empty((like.shape[0] * n, *like.shape[1:]), dtype=like.dtype, device=like.device)
+            return self._ip_noise_full(full).chunk(n)[idx]
+        return self._ip_noise_full(like)
+
+    def _ip_noise_full(self, like):
         if self.noise_on_host:
             return torch.randn(like.shape, dtype=torch.float32).to(device=like.device, dtype=like.dtype)
         return torch.randn_like(like)

@@ -161,7 +161,12 @@ class AnimationPipeline:
                  negative_prompt=None, num_videos_per_prompt=1, eta=0.0, generator=None, latents=None,
                  output_type="tensor", return_dict=True, callback=None, callback_steps=1, latents_dtype=torch.float16,
                  video_batch=None, use_outpaint=False, use_ip_plus_cross_attention=False, use_fps_condition=False,
-                 ip_plus_condition="image", prompt_embeds=None, sam_features=None, trace=None, **kwargs):
+                 ip_plus_condition="image", prompt_embeds=None, sam_features=None, trace=None, frame_shard=None,
+                 **kwargs):
+        """``frame_shard`` (imagine360_amd.dist.FrameShard): this rank denoises a contiguous chunk of the frames (BASELINE
+        configs 4 / 5); all ranks must be called with the same seeds and inputs.  Noise is drawn for the whole clip and
+        cut, the VAE encodes / the loop runs / the VAE decodes only the local frames, the motion modules exchange tokens
+        with one all-to-all each way, and the decoded frames are all-gathered at the end (the only other collective)."""
         device = self.device
         vb = video_batch
         assert use_outpaint and use_ip_plus_cross_attention, "the dual pipeline runs with use_outpaint and the IP adapter"
@@ -179,8 +184,17 @@ class AnimationPipeline:
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         steps_host = self.scheduler._timesteps_host
         pano_latent, pers_latent = self.init_noise(1, f, H // 8, W // 8, ps // 8, ps // 8, cameras, device, latents_dtype)
+        sh = frame_shard
+        if sh is not None:
+            # every rank drew the whole clip's noise from the same seed (and below encodes all frames, so the VAE
+            # posterior samples are the unsharded run's): cut to the local frames
+            pano_latent, pers_latent = sh.take(pano_latent, 2).contiguous(), sh.take(pers_latent, 3).contiguous()
         pano_ml, pano_mask_l = self.prepare_masked_latents_pano(f, pano_pix_masked, pano_mask.to(device))
         pers_ml, pers_mask_l = self.prepare_masked_latents_pers(f, pers_pix_masked, pers_masks.to(device))
+        if sh is not None:
+            pano_ml, pano_mask_l = sh.take(pano_ml, 2), sh.take(pano_mask_l, 2)
+            pers_ml, pers_mask_l = sh.take(pers_ml, 3), sh.take(pers_mask_l, 3)
+            self.mv_base_model.set_frame_shard(sh)
 
         if prompt_embeds is not None:
             text_pano, text_pers = prompt_embeds
@@ -207,7 +221,7 @@ class AnimationPipeline:
         in_pers = torch.cat([torch.cat((pers_latent, pers_mask_l.to(dt), pers_ml.to(dt)), dim=2)] * 2)
 
         graphed = None
-        if self.use_graph and self.rng == "device" and pano_latent.is_cuda and trace is None and callback is None:
+        if self.use_graph and self.rng == "device" and pano_latent.is_cuda and trace is None and callback is None and sh is None:
             from .graph_step import GraphedDenoiseStep
             inputs = dict(latents=in_pers, pano_latent=in_pano, prompt_embd=text_pers, pano_prompt_embd=text_pano,
                           fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers, reference_images_clip_feat_pano=feat_pano,
@@ -235,6 +249,11 @@ class AnimationPipeline:
 
         video = self.decode_latents(self.padding_pano(pano_latent, latent=True))
         video = self.unpadding_pano(video)
+        if sh is not None:                  # latent / video boundary: the only collective besides the motion-module exchanges
+            self.mv_base_model.set_frame_shard(None)
+            video = sh.gather_frames(torch.from_numpy(np.ascontiguousarray(video)).to(device), 2).cpu().numpy()
+            pano_latent = sh.gather_frames(pano_latent, 2)
+            pers_latent = sh.gather_frames(pers_latent, 3)
         if output_type == "tensor":
             video = torch.from_numpy(np.ascontiguousarray(video))
         self.last_latents = (pano_latent, pers_latent)

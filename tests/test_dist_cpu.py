@@ -112,3 +112,77 @@ def _motion_job(rank, world):
 def test_frame_sharded_motion_module_matches_unsharded():
     out = _run(_motion_job)
     assert out[0] < 1e-5 and out[1] < 1e-5
+
+
+def _mv_sharded_job(rank, world):
+    """Whole dual-branch forward (both UNets, 7 WarpAttn, all motion modules) with the frames cut over the ranks ==
+    this rank's frames of the unsharded forward.  Reduced width (channels / 10), 4 frames, 256 x 512 panorama."""
+    import random
+    import _emu_kernels as E
+    from imagine360_amd import configs, synthetic as S
+    from imagine360_amd.dist import FrameShard, shard_mv_inputs
+    mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True)
+    mv.noise_on_host = True
+    frames = 4
+    inp = S.mv_inputs(frames=frames, pano_hw=(32, 64), pers_hw=(16, 16), seed=5, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    kw = dict(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True)
+    with E.patched_kernels():
+        torch.manual_seed(3)
+        random.seed(3)
+        pers_full, pano_full = mv(**kw, **inp)
+        sh = FrameShard(frames)
+        mv.set_frame_shard(sh)
+        torch.manual_seed(3)              # every rank replays the unsharded run's RNG stream (IP noise, WarpAttn coins)
+        random.seed(3)
+        pers_loc, pano_loc = mv(**kw, **shard_mv_inputs(inp, sh))
+        mv.set_frame_shard(None)
+        gathered = sh.gather_frames(pano_loc.contiguous(), 2)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    return [rel(pano_loc, sh.take(pano_full, 2)), rel(pers_loc, sh.take(pers_full, 3)), rel(gathered, pano_full),
+            list(pano_loc.shape), list(pers_loc.shape)]
+
+
+def test_frame_sharded_mv_forward_matches_unsharded():
+    out = _run(_mv_sharded_job)
+    for r in range(2):
+        assert out[r][0] < 1e-5 and out[r][1] < 1e-5 and out[r][2] < 1e-5, out[r]
+        assert out[r][3] == [2, 4, 2, 32, 64] and out[r][4] == [2, 20, 4, 2, 16, 16]
+
+
+def _cfg_split_job(rank, world):
+    """BASELINE config 5 layout at world size 2: rank 0 runs the unconditional CFG half, rank 1 the text half (frame
+    shards of one rank each); after the pairwise exchange both hold the CFG-batched prediction of the unsplit model."""
+    import random
+    import _emu_kernels as E
+    from imagine360_amd import configs, synthetic as S
+    from imagine360_amd.dist import cfg_frame_layout, cfg_half_inputs, exchange_cfg_halves, shard_mv_inputs
+    mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True)
+    mv.noise_on_host = True
+    inp = S.mv_inputs(frames=2, pano_hw=(32, 64), pers_hw=(16, 16), seed=6, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    kw = dict(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True)
+    half, shard, pair = cfg_frame_layout(2)
+    assert half == rank and shard.world == 1 and shard.local == 2
+    with E.patched_kernels():
+        torch.manual_seed(4)
+        random.seed(4)
+        pers_full, pano_full = mv(**kw, **inp)
+        mv.set_frame_shard(shard)
+        torch.manual_seed(4)
+        random.seed(4)
+        # the IP-adapter noise is drawn for the CFG batch: draw the full batch's stream on both ranks, keep this half
+        mv._ip_noise_half = (half, 2)
+        pers_h, pano_h = mv(**kw, **shard_mv_inputs(cfg_half_inputs(inp, half), shard))
+        mv._ip_noise_half = None
+        mv.set_frame_shard(None)
+        pano_both, pers_both = exchange_cfg_halves(pano_h, pair), exchange_cfg_halves(pers_h, pair)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    return [rel(pano_both, pano_full), rel(pers_both, pers_full), list(pano_h.shape)]
+
+
+def test_cfg_halves_on_two_rank_groups_match_the_cfg_batched_forward():
+    out = _run(_cfg_split_job)
+    for r in range(2):
+        assert out[r][0] < 1e-5 and out[r][1] < 1e-5, out[r]
+        assert out[r][2] == [1, 4, 2, 32, 64]
