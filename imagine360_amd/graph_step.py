@@ -6,7 +6,31 @@ replayed: per step the host only refreshes four tiny device buffers (timestep, (
 coins drawn from Python's RNG in the reference's order) and calls replay().  The per-step IP-adapter noise is drawn
 inside the graph from torch's device generator (graph-safe philox state), like the reference's GPU path.
 """
+import random
+
 import torch
+
+
+class _PinnedUploads:
+    """Small host -> device parameter uploads that do not stall the host: a ring of pinned staging slots, one event per
+    slot (a copy from pageable memory is a memcpy + stream synchronise in PyTorch, i.e. one full host-device sync per
+    upload per step)."""
+
+    def __init__(self, like, slots=8):
+        self.slots = [torch.empty(like.shape, dtype=like.dtype, pin_memory=True) for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def upload(self, dst, values):
+        k = self.i % len(self.slots)
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copy that last used this slot has been consumed
+        self.slots[k].copy_(torch.as_tensor(values, dtype=dst.dtype))
+        dst.copy_(self.slots[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
 
 
 class GraphedDenoiseStep:
@@ -23,7 +47,12 @@ class GraphedDenoiseStep:
         self.coef = torch.zeros(3, dtype=torch.float32, device=dev)
         self.use_fps = use_fps
         self.graph = None
-        mv.draw_coins(dev)                       # allocates the device coin buffer (consumes 7 Python draws)
+        self._up_t, self._up_c = _PinnedUploads(self.timestep), _PinnedUploads(self.coef)
+        # Building the graph must not consume randomness: the warm-up steps draw device noise (the per-step IP-adapter
+        # noise) and allocating the coin buffer used to take 7 Python draws, which shifted the streams of the default
+        # (graphed) pipeline relative to the eager one and to the reference for the same seeds.
+        py_state, cuda_state = random.getstate(), torch.cuda.get_rng_state(dev)
+        mv.draw_coins(dev)                       # allocates the device coin buffer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):            # eager warm-up off the default stream (caches, allocator)
@@ -43,6 +72,9 @@ class GraphedDenoiseStep:
         # the eager warm-up steps advanced the latents; capture itself executes nothing: start from the given ones
         self.pano_lat.copy_(init_pano)
         self.pers_lat.copy_(init_pers)
+        random.setstate(py_state)
+        torch.cuda.synchronize()
+        torch.cuda.set_rng_state(cuda_state, dev)
 
     def _body(self):
         inp = self.inp
@@ -62,6 +94,8 @@ class GraphedDenoiseStep:
         finally:
             self.mv.coins_preloaded = was
         self.pred_pano, self.pred_pers = pred_pano, pred_pers          # static graph-pool tensors (inspection / tests)
+        ldt = self.pano_lat.dtype            # latents may be kept in another 16-bit type than the model (the reference promotes)
+        pred_pano, pred_pers = pred_pano.to(ldt), pred_pers.to(ldt)
         new_pano = self.sch.fused_cfg_step(pred_pano[0:1], pred_pano[1:2], self.g, None, self.pano_lat, coef_dev=self.coef)
         new_pers = self.sch.fused_cfg_step(pred_pers[0:1], pred_pers[1:2], self.g, None, self.pers_lat, coef_dev=self.coef)
         self.pano_lat.copy_(new_pano)
@@ -69,9 +103,8 @@ class GraphedDenoiseStep:
 
     def _upload(self, t_host, draw=True):
         cx, cv = self.sch.coefficients(t_host)
-        # fresh pageable host tensors (staged at call time): safe when the host runs steps ahead of the GPU
-        self.timestep.copy_(torch.tensor([int(t_host)], dtype=torch.int64))
-        self.coef.copy_(torch.tensor([self.g, cx, cv], dtype=torch.float32))
+        self._up_t.upload(self.timestep, [int(t_host)])
+        self._up_c.upload(self.coef, [self.g, cx, cv])
         if draw:
             self.mv.draw_coins(self.timestep.device)
 

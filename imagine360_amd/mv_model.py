@@ -146,10 +146,23 @@ class MultiViewBaseModel(nn.Module):
         front keeps the stream identical.  They go to a small device tensor the attention kernels read."""
         if self._coins_dev is None or self._coins_dev.device != torch.device(device):
             self._coins_dev = torch.zeros(8, dtype=torch.int32, device=device)
-        # a fresh pageable host tensor per step: the runtime stages it at call time, so the host may run ahead of
-        # the GPU without a later step's coins overwriting an upload that has not executed yet
-        coins = torch.tensor([1 if random.random() < 0.4 else 0 for _ in range(7)] + [0], dtype=torch.int32)
-        self._coins_dev.copy_(coins)
+        coins = [1 if random.random() < 0.4 else 0 for _ in range(7)] + [0]
+        if self._coins_dev.is_cuda:
+            # pinned staging ring + non-blocking copy: no host-device sync per step (a copy from pageable memory is one)
+            if getattr(self, "_coin_ring", None) is None:
+                self._coin_ring = ([torch.empty(8, dtype=torch.int32, pin_memory=True) for _ in range(8)], [None] * 8, 0)
+            slots, events, i = self._coin_ring
+            k = i % len(slots)
+            if events[k] is not None:
+                events[k].synchronize()
+            slots[k].copy_(torch.tensor(coins, dtype=torch.int32))
+            self._coins_dev.copy_(slots[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events[k] = ev
+            self._coin_ring = (slots, events, i + 1)
+        else:
+            self._coins_dev.copy_(torch.tensor(coins, dtype=torch.int32))
         return self._coins_dev
 
     def _rig(self, cameras, m):

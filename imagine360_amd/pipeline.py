@@ -260,5 +260,5 @@ class AnimationPipeline:
         return AnimationPipelineOutput(videos=video) if return_dict else video
 
     def _cfg_step(self, pred, g, t, latent):
-        u, c = pred.chunk(2)
+        u, c = pred.to(latent.dtype).chunk(2)          # latents_dtype may differ from the model dtype (the reference promotes)
         return self.scheduler.fused_cfg_step(u, c, g, t, latent)

@@ -744,7 +744,9 @@ class UNet3DConditionModel(nn.Module):
         def build():
             t = self.temporal_proj(feats.to(self.dtype))
             return self.image_proj_model(t.reshape(t.shape[0], -1, t.shape[-1]))
-        params = (feats, self.image_proj_model.latents, self.image_proj_model.proj_out.weight)
+        # keyed on the features and on EVERY adapter parameter: a partial load_state_dict or an in-place LoRA merge into
+        # any of them must rebuild the tokens
+        params = (feats, *self.temporal_proj.parameters(), *self.image_proj_model.parameters())
         return self._ip_cache.get("ip", params, build)
 
     def relpos_tokens(self, rel_pos, pitchs, n_tokens):
