@@ -116,6 +116,55 @@ static int launch_ln(const void* x, const void* gamma, const void* beta, const v
     return IM360_OK;
 }
 
+
+// ---- row softmax with a logit scale: y[r, :] = softmax(x[r, :] * scale), fp32 inside, 16-bit in / out.
+//      The VAE's single-head d = 512 AttentionBlock (diffusers/models/attention.py:247-379: baddbmm -> softmax(fp32)
+//      -> bmm) runs as GEMM -> this kernel -> GEMM; its score matrix is tokens x tokens of ONE image, read and written
+//      once here.  One workgroup (256 threads) per row, three passes over the row held in L2 / registers.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, long cols,
+                                                            long x_rs, long y_rs, float scale) {
+    __shared__ float red[8];
+    const long r = blockIdx.x;
+    const T* xr = x + r * x_rs;
+    T* yr = y + r * y_rs;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long nch = cols >> 3;
+    float m = -INFINITY;
+    for (long c = tid; c < nch; c += 256) {
+        float f[8];
+        unpack8<T>(*(const uint4*)(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, f[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    __syncthreads();
+    const float s2 = scale * 1.4426950408889634f, m2 = m * 1.4426950408889634f;
+    float sum = 0.f;
+    for (long c = tid; c < nch; c += 256) {
+        float f[8];
+        unpack8<T>(*(const uint4*)(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f(fmaf(f[e], s2, -m2));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wid] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (long c = tid; c < nch; c += 256) {
+        float f[8];
+        unpack8<T>(*(const uint4*)(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_exp2f(fmaf(f[e], s2, -m2)) * inv;
+        *(uint4*)(yr + c * 8) = pack8<T>(f);
+    }
+}
+
 }  // namespace im360
 
 // y[r] = LN(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod]; pre/post optional
@@ -154,6 +203,32 @@ extern "C" int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, in
         hipLaunchKernelGGL((geglu_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)h, (_Float16*)out, (long)rows, (int)(I / 8));
     else {
         im360_set_error("geglu: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// y[r, c] = softmax_c(x[r, c] * scale) over `cols` (a multiple of 8) columns of `rows` rows; row strides in elements
+// (multiples of 8); fp32 arithmetic.  x == y (in place) is allowed.
+extern "C" int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
+                                  float scale, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && y, "softmax_rows: null pointer");
+    IM360_CHECK_ARG(rows > 0 && cols > 0 && (cols % 8) == 0 && (x_rs % 8) == 0 && (y_rs % 8) == 0 && x_rs >= cols && y_rs >= cols,
+                    "softmax_rows: cols / row strides must be positive multiples of 8");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "softmax_rows: misaligned pointer");
+    IM360_CHECK_ARG(rows <= 0x7fffffffL, "softmax_rows: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_MISC, stream);
+    if (dtype == 0)
+        hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3((unsigned)rows), dim3(256), 0, s, (const __bf16*)x, (__bf16*)y,
+                           (long)rows, (long)cols, (long)x_rs, (long)y_rs, scale);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3((unsigned)rows), dim3(256), 0, s, (const _Float16*)x,
+                           (_Float16*)y, (long)rows, (long)cols, (long)x_rs, (long)y_rs, scale);
+    else {
+        im360_set_error("softmax_rows: dtype %d unsupported", dtype);
         return IM360_ERR_UNSUPPORTED;
     }
     IM360_CHECK_LAUNCH();

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
     "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
     "im360_linear_geglu": (_INT, [_PTR] * 4 + [_I64] * 3 + [_INT, _PTR]),
+    "im360_softmax_rows": (_INT, [_PTR] * 2 + [_I64] * 4 + [_F32, _INT, _PTR]),
     "im360_tuning_set": (_INT, [_INT, _INT]),
     "im360_prof_enable": (None, [ctypes.c_uint]),
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
@@ -288,6 +289,36 @@ def linear_geglu(x, w_packed, bias_packed, inner):
     _check(rc, "im360_linear_geglu")
     _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()))
     return y
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    """softmax(x * scale) over the last dim of a 2-D tensor (fp32 inside); ``out`` may be ``x`` (in place)."""
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x)
+    rc = lib().im360_softmax_rows(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(scale),
+                                  _dt(x), _stream())
+    _check(rc, "im360_softmax_rows")
+    _count("misc", 0.0, 2 * x.element_size() * x.numel())
+    return out
+
+
+def single_head_attention(q, k, v, scale):
+    """softmax(q k^T * scale) v for ONE head of any width (the VAE's d = 512 AttentionBlock): scores through the MFMA
+    GEMM kernel (k as the weight operand), fp32 row softmax of the 16-bit scores, probabilities x v through the GEMM
+    kernel again -- the reference's own op order (baddbmm -> softmax(float) -> bmm, diffusers/models/attention.py:
+    336-364).  q [Nq, d], k / v [Nk, d]; d % 32 == 0, Nk % 32 == 0."""
+    nq, d = q.shape
+    nk = k.shape[0]
+    if d % 32 or nk % 32:
+        raise NotImplementedError(f"single_head_attention: d={d} and Nk={nk} must be multiples of 32")
+    kw = k.contiguous().reshape(nk, 1, d) if nk % 128 == 0 else pack_conv_weight(k.reshape(nk, d, 1, 1))
+    s = conv2d(q.contiguous().reshape(nq, 1, 1, d), kw, nk).reshape(nq, nk)
+    softmax_rows(s, scale, out=s)
+    vt = v.t().contiguous()
+    vw = vt.reshape(d, 1, nk) if d % 128 == 0 else pack_conv_weight(vt.reshape(d, nk, 1, 1))
+    return conv2d(s.reshape(nq, 1, 1, nk), vw, d).reshape(nq, d)
 
 
 # ------------------------------------------------------------------------------------------ misc

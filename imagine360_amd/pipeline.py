@@ -141,11 +141,14 @@ class AnimationPipeline:
         mk = F.interpolate(mk, size=(m, lat.shape[-2], lat.shape[-1])).unsqueeze(3)
         return lat, mk.permute(0, 2, 3, 1, 4, 5).to(lat.device)
 
-    def decode_latents(self, latents):
-        """(:301-313) per-frame VAE decode -> float32 numpy in [0, 1], [b, 3, f, H, W]."""
+    def decode_latents(self, latents, frames_per_call=8):
+        """(:301-313) VAE decode -> float32 numpy in [0, 1], [b, 3, f, H, W].  The reference decodes frame by frame; every
+        VAE op is per image (GroupNorm, conv, the mid-block attention), so decoding ``frames_per_call`` frames per call
+        gives the same numbers with 1/8 of the launches."""
         b, c, f, h, w = latents.shape
         z = (latents / VAE_SCALE).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
-        frames = [self.vae.decode(z[i:i + 1].to(self.vae.dtype)).sample for i in range(z.shape[0])]
+        frames = [self.vae.decode(z[i:i + frames_per_call].to(self.vae.dtype), batched=True).sample
+                  for i in range(0, z.shape[0], frames_per_call)]
         video = torch.cat(frames).reshape(b, f, 3, h * 8, w * 8).permute(0, 2, 1, 3, 4)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()
 

@@ -3,14 +3,15 @@ resnet.py:77-190, 367-495, attention.py:247-379) on channels-last HIP kernels, w
 state-dict keys and the ``encode(...).latent_dist.sample()`` / ``decode(z).sample`` surface.
 
 The convolutions and GroupNorm+SiLU passes run on the same kernels as the UNet.  The single-head
-d = C (512) mid-block attention is the one op still left to torch (bmm / fp32 softmax / bmm): the MFMA
-flash kernel covers head dims 32 and 64 only -- see DESIGN.md "gaps".
+d = C (512) mid-block attention runs as GEMM -> fp32 row softmax -> GEMM on the HIP kernels
+(``kernels.single_head_attention``), the reference's own op order.
 """
 from dataclasses import dataclass
 
 import torch
 import torch.nn as nn
 
+from . import kernels
 from .layers import InflatedConv3d as Conv2dCL
 from .layers import InflatedGroupNorm as GroupNormCL
 
@@ -52,12 +53,8 @@ class AttentionBlock(nn.Module):
         n, h, w, c = x.shape
         t = self.group_norm.forward_cl(x).reshape(n, h * w, c)
         q, k, v = self.query(t), self.key(t), self.value(t)
-        out = torch.empty_like(q)
-        rows = max(1, (1 << 28) // max(h * w, 1))            # bound the fp32 score slab to ~1 GiB
-        for i in range(n):
-            for r0 in range(0, h * w, rows):
-                s = torch.matmul(q[i, r0:r0 + rows], k[i].transpose(0, 1)) * (c ** -0.5)
-                out[i, r0:r0 + rows] = torch.matmul(torch.softmax(s.float(), dim=-1).to(q.dtype), v[i])
+        # one head of width c (512): QK^T and PV on the MFMA GEMM kernel, fp32 row softmax between them, per image
+        out = torch.stack([kernels.single_head_attention(q[i], k[i], v[i], c ** -0.5) for i in range(n)])
         return self.proj_attn(out).reshape(n, h, w, c) + x
 
 
@@ -231,9 +228,11 @@ class AutoencoderKL(nn.Module):
         post.sample_on_host = self.sample_on_host
         return AutoencoderKLOutput(latent_dist=post) if return_dict else (post,)
 
-    def decode(self, z, return_dict=True):
+    def decode(self, z, return_dict=True, batched=False):
+        """``batched``: decode the whole batch in one pass even when slicing is enabled (same numbers: every op of the
+        decoder is per image; slicing only bounds the reference's activation memory)."""
         zc = z.to(self.dtype).permute(0, 2, 3, 1).contiguous()
-        if self.use_slicing and zc.shape[0] > 1:
+        if self.use_slicing and zc.shape[0] > 1 and not batched:
             dec = torch.cat([self.decode_cl(s) for s in zc.split(1)])
         else:
             dec = self.decode_cl(zc)

@@ -117,6 +117,12 @@ int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, vo
 int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
                        int64_t M, int64_t K, int64_t I, int dtype, void* stream);
 
+/* y[r, :] = softmax(x[r, :] * scale), fp32 arithmetic on 16-bit rows (cols and the row strides multiples of 8; in place
+ * allowed).  With two launches of im360_conv_fwd as GEMMs it forms the single-head d = 512 attention of the VAE.
+ * Replaces: AttentionBlock.forward's softmax(attention_scores.float()), diffusers/models/attention.py:336-364. */
+int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
+                       float scale, int dtype, void* stream);
+
 /* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 allow the 256x320 conv tile,
  * 2 force 32-channel K steps, 3 scalar temporal attention, 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring
  * kernel (asm LDS-DMA), 2 the same with the LDS-DMA builtin).  Defaults are the measured best; the IM360_* environment

@@ -136,6 +136,14 @@ def geglu(h):
     return (a * F.gelu(g)).to(h.dtype)
 
 
+def softmax_rows(x, scale=1.0, out=None):
+    y = torch.softmax(x.float() * scale, dim=-1).to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def pack_geglu(weight, bias):
     return weight, bias
 
@@ -145,7 +153,7 @@ def linear_geglu(x, w, b, inner):
 
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
-          "conv2d", "circular_pad_w", "cfg_ddim_update"]
+          "conv2d", "circular_pad_w", "cfg_ddim_update", "softmax_rows"]
 
 
 @contextlib.contextmanager
