@@ -37,14 +37,21 @@ struct AttnParams {
     float scale_log2;    // logit scale * log2(e)
     float out_scale;     // multiplies the normalised result
     int accumulate;      // out += result instead of out = result
+    // optional SECOND key/value set of the same queries (DUAL kernels): out = out_scale * attn(q, k, v) + out_scale2 *
+    // attn(q, k2, v2), two independent softmaxes -- the text + IP-adapter cross attention in ONE launch
+    const void* k2; const void* v2;
+    int Nk2;
+    long k2_bs, k2_rs, v2_bs, v2_rs;
+    float out_scale2;
 };
 
 constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between rescales
 
-template <typename T, int D, int NW, int QB, bool HAS_BIAS>
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
+    static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
     constexpr int VP = D == 64 ? 96 : 32;   // V tile pitch: 192-B / 64-B rows -> rows r..r+3 hit 4 distinct 64-B bank windows
@@ -79,8 +86,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int q0 = (int)(lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
 
     const T* qb_ = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
+    // the key / value set being processed (DUAL kernels switch to the second set after the first)
     const T* kb_ = (const T*)p.k + (long)(b / p.kv_group) * p.k_bs + (long)h * D;
     const T* vb = (const T*)p.v + (long)(b / p.kv_group) * p.v_bs + (long)h * D;
+    long set_k_rs = p.k_rs, set_v_rs = p.v_rs;
+    int set_nk = p.Nk;
     const T* bias = (const T*)p.bias;
     if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) bias = (const T*)p.bias_alt;
 
@@ -114,16 +124,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         l_run[qb] = 0.f;
     }
 
-    const int ntiles = (p.Nk + KVB - 1) / KVB;
-    const bool ragged = (p.Nk % KVB) != 0;      // the last tile is partial: clamp its rows, mask its scores
+    int ntiles = (set_nk + KVB - 1) / KVB;
+    bool ragged = (set_nk % KVB) != 0;          // the last tile is partial: clamp its rows, mask its scores
     u32x4 kreg[CLD], vreg[CLD];
 
     // per-thread staging slots: thread tid owns (row, 16-byte chunk) slots tid + i * NT of a tile (rows RSTEP apart),
     // so one source pointer per operand advanced by a tile per load is all the address math
     const int srow = tid / (D / 8), sc8 = tid % (D / 8);
-    const T* ksrc = kb_ + (long)srow * p.k_rs + sc8 * 8;
-    const T* vsrc = vb + (long)srow * p.v_rs + sc8 * 8;
-    const long k_tile = (long)KVB * p.k_rs, v_tile = (long)KVB * p.v_rs;
+    const T* ksrc = kb_ + (long)srow * set_k_rs + sc8 * 8;
+    const T* vsrc = vb + (long)srow * set_v_rs + sc8 * 8;
+    long k_tile = (long)KVB * set_k_rs, v_tile = (long)KVB * set_v_rs;
     T* const kdst = k_lds2 + srow * KP + sc8 * 8;
     T* const vdst = v_lds2 + srow * VP + sc8 * 8;
 
@@ -135,12 +145,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int kv0 = t * KVB;
         static_for<CLD>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            const T* ks = ksrc + (long)(i * RSTEP) * p.k_rs;
-            const T* vs = vsrc + (long)(i * RSTEP) * p.v_rs;
+            const T* ks = ksrc + (long)(i * RSTEP) * set_k_rs;
+            const T* vs = vsrc + (long)(i * RSTEP) * set_v_rs;
             if (clamp) {
-                const long rr = min(kv0 + srow + i * RSTEP, p.Nk - 1);
-                ks = kb_ + rr * p.k_rs + sc8 * 8;
-                vs = vb + rr * p.v_rs + sc8 * 8;
+                const long rr = min(kv0 + srow + i * RSTEP, set_nk - 1);
+                ks = kb_ + rr * set_k_rs + sc8 * 8;
+                vs = vb + rr * set_v_rs + sc8 * 8;
             }
             kreg[i] = *(const u32x4*)ks;
             vreg[i] = *(const u32x4*)vs;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, p.Nk - 4);     // Nk % 4 == 0 (checked on the host)
+                        const int key0 = min(kv0 + kb * 32 + 8 * g + 4 * hi, set_nk - 4);     // Nk % 4 == 0 (checked on the host)
                         bw[qb][QK_ALL ? kb : 0][g] = *(const uint2*)(bias + (long)qrow[qb] * p.bias_rs + key0);
                     }
             }
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (MASKED) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (kv0 + kb * 32 + mfma32_row(r, hi) >= p.Nk) sv[r] = -INFINITY;
+                        if (kv0 + kb * 32 + mfma32_row(r, hi) >= set_nk) sv[r] = -INFINITY;
                 }
             }
             float mloc = s[qb][K0][0];
@@ -302,22 +312,55 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
 
-    load_tile(0);
-    store_tile(0);
-    if (ntiles > 1) load_tile(1);
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();                 // tile t is visible; every wave is done with tile t-1 (buffer (t+1)&1)
-        if (t + 1 < ntiles) store_tile((t + 1) & 1);
-        if (t + 2 < ntiles) load_tile(t + 2);      // in flight during the whole compute phase below
-        if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
-        else tile_body(t, std::false_type{});
+    auto run_set = [&]() {
+        load_tile(0);
+        store_tile(0);
+        if (ntiles > 1) load_tile(1);
+        for (int t = 0; t < ntiles; ++t) {
+            __syncthreads();                 // tile t is visible; every wave is done with tile t-1 (buffer (t+1)&1)
+            if (t + 1 < ntiles) store_tile((t + 1) & 1);
+            if (t + 2 < ntiles) load_tile(t + 2);      // in flight during the whole compute phase below
+            if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
+            else tile_body(t, std::false_type{});
+        }
+    };
+    run_set();
+    f32x16 osum[DUAL ? DV : 1];          // DUAL: out_scale * (normalised result of the first set)
+    if constexpr (DUAL) {
+        const float l_tot = l_run[0] + __shfl_xor(l_run[0], 32);
+        const float inv = p.out_scale / l_tot;
+#pragma unroll
+        for (int i = 0; i < DV; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                osum[i][r] = o[0][i][r] * inv;
+                o[0][i][r] = 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[0][r] = 0.f;
+        m_sc[0] = 0.f;
+        l_run[0] = 0.f;
+        // second key / value set: same queries, its own softmax
+        kb_ = (const T*)p.k2 + (long)(b / p.kv_group) * p.k2_bs + (long)h * D;
+        vb = (const T*)p.v2 + (long)(b / p.kv_group) * p.v2_bs + (long)h * D;
+        set_k_rs = p.k2_rs;
+        set_v_rs = p.v2_rs;
+        set_nk = p.Nk2;
+        ntiles = (set_nk + KVB - 1) / KVB;
+        ragged = (set_nk % KVB) != 0;
+        ksrc = kb_ + (long)srow * set_k_rs + sc8 * 8;
+        vsrc = vb + (long)srow * set_v_rs + sc8 * 8;
+        k_tile = (long)KVB * set_k_rs;
+        v_tile = (long)KVB * set_v_rs;
+        __syncthreads();                     // every wave is done with the first set's last tile
+        run_set();
     }
 
     // ---- epilogue: normalise, optional accumulate, store 4 consecutive channels per (lane, group)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
-        const float inv = p.out_scale / l_tot;
+        const float inv = (DUAL ? p.out_scale2 : p.out_scale) / l_tot;
         if (q_valid[qb]) {
             T* ob = (T*)p.out + (long)b * p.o_bs + (long)qrow[qb] * p.o_rs + (long)h * D;
 #pragma unroll
@@ -326,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int g = 0; g < 4; ++g) {
                     float f[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = o[qb][dvb][4 * g + j] * inv;
+                    for (int j = 0; j < 4; ++j) f[j] = o[qb][dvb][4 * g + j] * inv + (DUAL ? osum[DUAL ? dvb : 0][4 * g + j] : 0.f);
                     uint2* dst = (uint2*)(ob + dvb * 32 + 8 * g + 4 * hi);
                     if (p.accumulate) {
                         const uint2 old = *dst;
@@ -367,6 +410,27 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
 
 template <typename T, int D>
 static int launch_attn(const AttnParams& p, hipStream_t stream) {
+    if (p.k2) {
+        if constexpr (D == 64) {
+            AttnParams q = p;
+            const int nw = q.Nq <= 32 ? 1 : (q.Nq <= 64 ? 2 : 4);
+            q.nqt = (q.Nq + 32 * nw - 1) / (32 * nw);
+            const long nblk = (long)q.B * q.H * q.nqt;
+            if (nblk > 0x7fffffffL) {
+                im360_set_error("attn_fwd: %ld workgroups exceed the grid limit", nblk);
+                return IM360_ERR_ARG;
+            }
+            dim3 grid((unsigned)nblk, 1, 1);
+            if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, 64, 1, 1, false, true>), grid, dim3(64), 0, stream, q);
+            else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, 64, 2, 1, false, true>), grid, dim3(128), 0, stream, q);
+            else hipLaunchKernelGGL((attn_fwd_kernel<T, 64, 4, 1, false, true>), grid, dim3(256), 0, stream, q);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        } else {
+            im360_set_error("attn_fwd2: two key/value sets need head dim 64");
+            return IM360_ERR_UNSUPPORTED;
+        }
+    }
     return p.bias ? launch_attn_b<T, D, true>(p, stream) : launch_attn_b<T, D, false>(p, stream);
 }
 
@@ -402,10 +466,44 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;
     p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = accumulate;
+    p.k2 = nullptr; p.v2 = nullptr; p.Nk2 = 0; p.k2_bs = p.k2_rs = p.v2_bs = p.v2_rs = 0; p.out_scale2 = 0.f;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, stream);
     if (dtype == 0) return D == 64 ? launch_attn<__bf16, 64>(p, s) : launch_attn<__bf16, 32>(p, s);
     if (dtype == 1) return D == 64 ? launch_attn<_Float16, 64>(p, s) : launch_attn<_Float16, 32>(p, s);
     im360_set_error("attn_fwd: dtype %d unsupported (0=bf16, 1=f16)", dtype);
+    return IM360_ERR_UNSUPPORTED;
+}
+
+// Two key / value sets for the same queries in ONE launch: out = out_scale * softmax(q k^T scale) v + out_scale2 *
+// softmax(q k2^T scale) v2 (head dim 64, no bias).  Strides as in im360_attn_fwd.
+extern "C" int im360_attn_fwd2(const void* q, const void* k, const void* v, const void* k2, const void* v2, void* out,
+                               int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Nk2, int64_t D,
+                               int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs,
+                               int64_t k2_bs, int64_t k2_rs, int64_t v2_bs, int64_t v2_rs, int64_t o_bs, int64_t o_rs,
+                               int64_t kv_group, float scale, float out_scale, float out_scale2, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(q && k && v && k2 && v2 && out, "attn_fwd2: null pointer");
+    IM360_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && Nk2 > 0, "attn_fwd2: empty problem");
+    IM360_CHECK_ARG(kv_group >= 1, "attn_fwd2: kv_group must be >= 1");
+    IM360_CHECK_ARG(D == 64, "attn_fwd2: head dim %ld unsupported (64)", (long)D);
+    IM360_CHECK_ARG(B * H <= 0x7fffffffL, "attn_fwd2: B*H too large");
+    IM360_CHECK_ARG((q_rs % 8) == 0 && (k_rs % 8) == 0 && (v_rs % 8) == 0 && (k2_rs % 8) == 0 && (v2_rs % 8) == 0 && (o_rs % 4) == 0 &&
+                    (q_bs % 8) == 0 && (k_bs % 8) == 0 && (v_bs % 8) == 0 && (k2_bs % 8) == 0 && (v2_bs % 8) == 0 && (o_bs % 4) == 0,
+                    "attn_fwd2: strides must keep 16-byte (q,k,v) / 8-byte (out) alignment");
+    IM360_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)k2 % 16) == 0 &&
+                    ((uintptr_t)v2 % 16) == 0 && ((uintptr_t)out % 8) == 0, "attn_fwd2: misaligned base pointer");
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v; p.bias = nullptr; p.out = out; p.bias_alt = nullptr; p.bias_sel = nullptr;
+    p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
+    p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
+    p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = 0;
+    p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = 0;
+    p.k2 = k2; p.v2 = v2; p.Nk2 = (int)Nk2; p.k2_bs = k2_bs; p.k2_rs = k2_rs; p.v2_bs = v2_bs; p.v2_rs = v2_rs; p.out_scale2 = out_scale2;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_ATTN, stream);
+    if (dtype == 0) return launch_attn<__bf16, 64>(p, s);
+    if (dtype == 1) return launch_attn<_Float16, 64>(p, s);
+    im360_set_error("attn_fwd2: dtype %d unsupported (0=bf16, 1=f16)", dtype);
     return IM360_ERR_UNSUPPORTED;
 }

@@ -18,6 +18,7 @@ _SIGNATURES = {
     "im360_abi_version": (_INT, []),
     "im360_last_error": (ctypes.c_char_p, []),
     "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR]),
+    "im360_attn_fwd2": (_INT, [_PTR] * 6 + [_I64] * 19 + [_F32, _F32, _F32, _INT, _PTR]),
     "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
@@ -124,6 +125,29 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
     _check(rc, "im360_attn_fwd")
     _count("attn", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
            + (0 if bias is None else bias.element_size() * Nq * Nk))
+    return out
+
+
+def attention2(q, k, v, k2, v2, heads, scale=None, out_scale=1.0, out_scale2=1.0, kv_group=1):
+    """out_scale * attn(q, k, v) + out_scale2 * attn(q, k2, v2) in ONE launch (two independent softmaxes over two
+    key / value sets: the text and the IP-adapter tokens of IPCrossAttention, animatediff/models/attention.py:113-148).
+    Shapes as in ``attention``; head dim 64."""
+    _dev(q, k, v, k2, v2)
+    B, Nq, C = q.shape
+    d = C // heads
+    for t in (k, v, k2, v2):
+        assert t.shape[0] * kv_group == B and t.shape[2] == C and t.stride(2) == 1
+    assert v.shape[1] == k.shape[1] and v2.shape[1] == k2.shape[1] and q.stride(2) == 1
+    out = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = d ** -0.5
+    rc = lib().im360_attn_fwd2(_p(q), _p(k), _p(v), _p(k2), _p(v2), _p(out), B, heads, Nq, k.shape[1], k2.shape[1], d,
+                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                               k2.stride(0), k2.stride(1), v2.stride(0), v2.stride(1), out.stride(0), out.stride(1),
+                               kv_group, float(scale), float(out_scale), float(out_scale2), _dt(q), _stream())
+    _check(rc, "im360_attn_fwd2")
+    _count("attn", 4.0 * B * heads * Nq * (k.shape[1] + k2.shape[1]) * d,
+           q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * (k.shape[1] + k2.shape[1]) * C))
     return out
 
 

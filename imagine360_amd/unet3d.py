@@ -158,9 +158,13 @@ class IPCrossAttention(QKVAttention):
         kt, vt, ki, vi = self.project_context(encoder_hidden_states)
         q = linear(self.to_q, hidden_states)
         ls = self.dim_head ** -0.5 if self._use_memory_efficient_attention_xformers else self.scale
-        out = kernels.attention(q, kt, vt, self.heads, scale=ls, kv_group=kv_group)
-        kernels.attention(q, ki, vi, self.heads, scale=ls, kv_group=kv_group, out=out, accumulate=True,
-                          out_scale=self.scale)
+        if self.dim_head == 64:
+            # both key / value sets in one launch: Q is read once, nothing is accumulated through HBM
+            out = kernels.attention2(q, kt, vt, ki, vi, self.heads, scale=ls, out_scale=1.0, out_scale2=self.scale, kv_group=kv_group)
+        else:
+            out = kernels.attention(q, kt, vt, self.heads, scale=ls, kv_group=kv_group)
+            kernels.attention(q, ki, vi, self.heads, scale=ls, kv_group=kv_group, out=out, accumulate=True,
+                              out_scale=self.scale)
         return self.out_proj(out, residual)
 
 

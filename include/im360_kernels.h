@@ -36,6 +36,17 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
                    const void* bias_alt, const void* bias_sel);
 
+/* Two key / value sets for the same queries in one launch (head dim 64, no bias):
+ *   out = out_scale * softmax(q k^T scale) v + out_scale2 * softmax(q k2^T scale) v2
+ * -- the text tokens and the IP-adapter tokens of the spatial cross attention, which the reference evaluates as two
+ * attention calls and an add.  Strides / kv_group as in im360_attn_fwd.
+ * Replaces: IPCrossAttention.forward, animatediff/models/attention.py:113-148. */
+int im360_attn_fwd2(const void* q, const void* k, const void* v, const void* k2, const void* v2, void* out,
+                    int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Nk2, int64_t D,
+                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs,
+                    int64_t k2_bs, int64_t k2_rs, int64_t v2_bs, int64_t v2_rs, int64_t o_bs, int64_t o_rs,
+                    int64_t kv_group, float scale, float out_scale, float out_scale2, int dtype, void* stream);
+
 /* Temporal self-attention over F <= 64 frames on token-major activations [B, F, P, heads*d]
  * (q, k, v are three views with common strides, e.g. slices of a fused QKV projection).
  * Replaces: VersatileAttention.forward -> Attention._attention (baddbmm/softmax/bmm) and its

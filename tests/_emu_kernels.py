@@ -33,6 +33,12 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
     return o.to(q.dtype)
 
 
+def attention2(q, k, v, k2, v2, heads, scale=None, out_scale=1.0, out_scale2=1.0, kv_group=1):
+    a = attention(q, k, v, heads, scale=scale, out_scale=out_scale, kv_group=kv_group).float()
+    b = attention(q, k2, v2, heads, scale=scale, out_scale=out_scale2, kv_group=kv_group).float()
+    return (a + b).to(q.dtype)
+
+
 def temporal_attention(qkv, B, Fr, P, heads):
     C = qkv.shape[1] // 3
     t = qkv.reshape(B, Fr, P, 3 * C).permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
@@ -153,7 +159,7 @@ def linear_geglu(x, w, b, inner):
 
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
-          "conv2d", "circular_pad_w", "cfg_ddim_update", "softmax_rows"]
+          "conv2d", "circular_pad_w", "cfg_ddim_update", "softmax_rows", "attention2"]
 
 
 @contextlib.contextmanager

@@ -75,6 +75,38 @@ def test_attention_two_kv_sets_accumulate(dt):
         assert rel(out, ref) < 1.5 * TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,Nq,group", [(4, 300, 2), (2, 1024, 1), (6, 40, 3)])
+def test_attention_two_kv_sets_one_launch(dt, B, Nq, group):
+    """im360_attn_fwd2: text (77 keys, ragged tile) + IP (64 keys) cross attention of one query in one launch, with the
+    per-video key / value sharing (kv_group) and an IP scale, against the oracle's two attention calls."""
+    H, D = 5, 64
+    C = H * D
+    q = q16(rnd(B, Nq, C, seed=70, scale=0.3), dt)
+    k1, v1, k2, v2 = (q16(rnd(B // group, n, C, seed=s), dt) for n, s in ((77, 71), (77, 72), (64, 73), (64, 74)))
+    rep = lambda t: t.repeat_interleave(group, 0)
+    for scale, s2 in ((1.0, 1.0), (D ** -0.5, 0.7)):
+        ref = OU.sdpa(q, rep(k1), rep(v1), H, scale=scale) + s2 * OU.sdpa(q, rep(k2), rep(v2), H, scale=scale)
+        out = K.attention2(q.to(dt).cuda(), k1.to(dt).cuda(), v1.to(dt).cuda(), k2.to(dt).cuda(), v2.to(dt).cuda(), H,
+                           scale=scale, out_scale2=s2, kv_group=group)
+        assert rel(out, ref) < 1.5 * TOL[dt]
+
+
+def test_softmax_rows_and_single_head_attention():
+    """The VAE's d = 512 single-head attention as GEMM -> fp32 row softmax -> GEMM (kernels.single_head_attention) and
+    the row-softmax kernel alone, against fp32 torch."""
+    g = torch.Generator().manual_seed(80)
+    for dt in DTYPES:
+        x = q16(torch.randn(37, 1000, generator=g) * 3, dt)
+        y = K.softmax_rows(x.to(dt).cuda(), 0.37)
+        assert rel(y, torch.softmax(x * 0.37, -1)) < TOL[dt]
+        q, k, v = (q16(torch.randn(n, 512, generator=g), dt) for n in (320, 1184, 1184))
+        s = (q @ k.t()).to(dt).float() * 512 ** -0.5                      # the reference rounds the scores to 16 bits
+        ref = torch.softmax(s, -1).to(dt).float() @ v
+        out = K.single_head_attention(q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda(), 512 ** -0.5)
+        assert rel(out, ref) < TOL[dt]
+
+
 def test_attention_softmax_rescale_branch():
     """Force the running max to jump in a late KV tile (spiked key) -- the online-softmax rescale path."""
     dt = torch.bfloat16
