@@ -35,6 +35,7 @@ struct ConvParams {
     long M;             // N * Hout * Wout
     int tiles_n;        // ceil(Cout / 128)
     long nblocks;
+    int halo_r, halo_seg, halo_pw, halo_p;      // halo kernel: output rows per tile, rows per image segment, patch width / pixels
     int dbg;            // ablation switches of the ring kernel (tools/ab_ring.py --ablate): 1 no LDS-DMA in the K loop, 2 no MFMA, 4 no fragment reads, 8 no epilogue
 };
 
@@ -803,6 +804,236 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
+// ---- 3x3 convolution from a halo'd pixel patch ----------------------------------------------------------------------
+// The kernels above stream one shifted copy of the pixel tile per tap: nine LDS-DMA loads of every activation, 9x the
+// input tensor through the L2 / fabric (profiles: fetch / input = 8.9 .. 14), and the CU's global -> LDS path (~21 B/clk)
+// carries 36 KB per 32-channel phase.  Here a tile is a RECTANGLE of output pixels -- 256 / Wout whole rows of width
+// Wout, inside one image or covering whole images -- and the K loop runs chunk-major: for each 32-channel chunk the
+// (rows + 2) x (Wout + 2) patch of input pixels (zeros outside the image) is loaded ONCE into LDS, the nine taps read
+// their shifted fragments out of it, and only the weights of (tap, chunk) stream per phase (20 KB).  Activations enter
+// LDS 1.3 - 2.0x instead of 9x.  Same ring / counted-vmcnt / interleaved-request / persistent-tile machinery as
+// conv_ring_kernel; the accumulation order over K is chunk-major here (tap-major there), so results agree with the other
+// kernels to fp32 summation order, not bit for bit.
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_halo_kernel(ConvParams p) {
+    constexpr int NT = 512, WN = 2, TM = 2, TN = 5, EPI = 0;
+    constexpr int BM = 256, BN = 320, BK = 32, ROWB = 64, KC = 2;
+    constexpr int APATCH = 33792;                    // bytes of one patch slot: up to 528 pixels x 64 B
+    constexpr int TILE_B = BN * ROWB;                // 20480
+    constexpr int LDB = 2;                           // + half a round for waves 0..3 (320 rows)
+    constexpr int A0 = 0, B0 = APATCH, B1 = B0 + TILE_B, A1 = B1 + TILE_B, B2 = A1 + APATCH, B3 = B2 + TILE_B;
+    constexpr int EPI_OFF = A1, EPI_BYTES = (NT / 64) * 32 * TN * 64;
+    constexpr int LDS_BYTES = EPI_OFF + EPI_BYTES > B3 + TILE_B ? EPI_OFF + EPI_BYTES : B3 + TILE_B;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+    const T* zero = (const T*)g_zero_chunk;
+    const uint32_t lds_u32 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
+
+    const long ntiles = p.nblocks;
+    const int per_xcd = gridDim.x / 8;
+    const long tile_first = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const long tile_step = gridDim.x;
+
+    const int R = p.halo_r, HS = p.halo_seg, PW = p.halo_pw, P = p.halo_p;
+    const int LA = (P * 4 + NT - 1) / NT;
+    const int nchunks = p.Cin / BK;
+    const int nph = 9 * nchunks;
+    const int nB = LDB + (wid_s < NT / 128 ? 1 : 0);       // weight pieces of this wave per phase
+
+    // ---- weight stream: rows srow (+128 i) of the cout tile, chunk position swizzled by the row (as in conv_ring_kernel)
+    const int srow = tid / 4;
+    const int pd8 = ((tid % 4) ^ ((srow / 4) & 3)) * 8;
+    const long bstride = (long)128 * 9 * p.Cin;
+    const T* bbase_ptr = wg;                         // + (n0 + srow) * 9 * Cin + pd8, per tile
+    int bq = 0;                                      // next phase whose weights are requested
+    long bcol = 0;                                   // its column offset in the packed weights: tap * Cin + chunk * 32
+    int btap = 0;
+    // ---- patch stream: piece k of a chunk = patch chunks k * 512 + tid (16 bytes each); its source pixel is recomputed
+    //      per piece (a few dozen scalar-ish instructions, <= 5 pieces per 9 phases) instead of held in registers
+    int ac = 0;                                      // chunk whose patch pieces are being requested
+    long grow0 = 0;                                  // first output row of the producer's tile in the (image, row) sequence
+    // (the destination is wave-uniform by construction; readfirstlane makes that provable inside the lane-masked patch pieces)
+    auto dma = [&](const T* src, int off) { lds_dma16_asm(src, __builtin_amdgcn_readfirstlane(lds_u32 + (uint32_t)off)); };
+    auto bslot = [&](int q) { const int s = q & 3; return s == 0 ? B0 : (s == 1 ? B1 : (s == 2 ? B2 : B3)); };
+    auto init_tile = [&](long tile) {
+        const long tm = tile / p.tiles_n;
+        const int n0 = (int)(tile % p.tiles_n) * BN;
+        bbase_ptr = wg + (long)(n0 + srow) * 9 * p.Cin + pd8;
+        bq = 0;
+        bcol = 0;
+        btap = 0;
+        ac = 0;
+        grow0 = tm * R;
+    };
+    auto issue_a = [&](int k) {                      // piece k of chunk `ac` -> patch slot ac & 1
+        const int e = k * NT + tid;
+        if (e < P * 4) {
+            const int pp = e >> 2, pos = e & 3;
+            const int prow = pp / PW, pcol = pp - prow * PW;
+            const int seg = prow / (HS + 2), ry = prow - seg * (HS + 2);
+            const long g = grow0 + (long)seg * HS;
+            const long n = g / p.Hout;
+            const int gy = (int)(g - n * p.Hout) + ry - 1, gx = pcol - 1 + p.x_off;
+            const bool ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+            const T* src = ok ? xg + (((n * p.Hin + gy) * p.Win + gx) * p.Cin + ((pos ^ ((pp >> 2) & 3)) << 3) + ac * BK) : zero;
+            dma(src, ((ac & 1) ? A1 : A0) + k * (NT * 16) + wid_s * 1024);
+        }
+    };
+    auto issue_b = [&](auto ic) {                    // piece i of phase `bq` -> weight slot bq & 3
+        constexpr int i = decltype(ic)::value;
+        const T* src = bbase_ptr + bcol + i * bstride;
+        if (i < LDB || wid_s < NT / 128) dma(src, bslot(bq) + i * (NT * 16) + wid_s * 1024);
+    };
+    auto next_b = [&]() {                            // phase bq + 1: next tap of the chunk, or tap 0 of the next chunk
+        ++bq;
+        bcol += p.Cin;
+        if (++btap == 9) {
+            btap = 0;
+            bcol += BK - 9L * p.Cin;
+        }
+    };
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
+    };
+    // fragment addressing: weights as in conv_ring_kernel; pixels through the patch
+    const int swz = (col / 4) & 3;
+    int koff[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) koff[kc] = ((kc * 2 + hi) ^ swz) * 16;
+    const int wrow = (wn * (TN * 32) + col) * ROWB;
+    int pix0[TM];                                    // patch pixel of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int l = wm * (TM * 32) + b * 32 + col;
+        const int yl = l / p.Wout, x = l - yl * p.Wout;
+        const int seg = yl / HS;
+        pix0[b] = (seg * (HS + 2) + (yl - seg * HS)) * PW + x;
+    }
+
+    auto prologue = [&]() {                          // patch of chunk 0 and the weights of phases 0, 1
+        for (int k = 0; k < LA; ++k) issue_a(k);
+        ac = 1;
+        static_for<LDB + 1>([&](auto ic) { issue_b(ic); });
+        next_b();
+        if (nph > 1) {
+            static_for<LDB + 1>([&](auto ic) { issue_b(ic); });
+            next_b();
+        }
+    };
+
+    long tile = tile_first;
+    if (tile >= ntiles) return;
+    init_tile(tile);
+    prologue();
+    for (;;) {
+        const long m0 = (tile / p.tiles_n) * BM;
+        const int n0 = (int)(tile % p.tiles_n) * BN;
+        asm volatile("s_barrier" ::: "memory");      // weight slot 2 / patch slot 1 overlap the previous epilogue's LDS
+        if (nph > 2) {
+            static_for<LDB + 1>([&](auto ic) { issue_b(ic); });
+            next_b();
+        }
+        f32x16 acc[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        int t = 0, ch = 0;                           // tap and chunk of the phase being computed
+        int tapoff = 0, tdx = 0;                     // tap offset inside the patch: (t / 3) * PW + t % 3, kept incrementally
+        int g1 = nB, g2 = nB;                        // request-group sizes of phases ph - 1, ph - 2 (phase -1 requested phase 2)
+        for (int ph = 0; ph < nph; ++ph) {
+            // everything up to the request group of phase ph - 3 has to be in LDS: the groups of ph - 2 and ph - 1 may fly
+            if (ph == 0) wait_vm(nph > 2 ? nB : 0);
+            else wait_vm(g1 + g2);
+            asm volatile("s_barrier" ::: "memory");
+            const bool req_b = ph + 3 < nph, req_a = t < LA && ch + 1 < nchunks;
+            const char* bt = lds + bslot(ph);
+            const char* at = lds + ((ch & 1) ? A1 : A0);
+            u32x4 xf[KC][TM], wf[KC][TN];
+            int xa[TM], xs[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int q = pix0[b] + tapoff;
+                xa[b] = q * ROWB;
+                xs[b] = (q >> 2) & 3;
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[0][b] = *(const u32x4*)(at + xa[b] + ((hi ^ xs[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wf[0][a] = *(const u32x4*)(bt + wrow + koff[0] + a * (32 * ROWB));
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xf[1][b] = *(const u32x4*)(at + xa[b] + (((2 + hi) ^ xs[b]) << 4));
+#pragma unroll
+            for (int a = 0; a < TN - 2; ++a) wf[1][a] = *(const u32x4*)(bt + wrow + koff[1] + a * (32 * ROWB));
+            __builtin_amdgcn_sched_barrier(0);
+            if (req_a) issue_a(t);                   // piece t of the next chunk's patch (t < LA <= 5)
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<KC * TN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, kc = j / TN, a = j % TN;
+                if constexpr (kc == 1 && a == 0) {
+#pragma unroll
+                    for (int a2 = TN - 2; a2 < TN; ++a2) wf[1][a2] = *(const u32x4*)(bt + wrow + koff[1] + a2 * (32 * ROWB));
+                }
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                constexpr int piece = (j % 2 == 1) ? j / 2 : -1;         // weight pieces after MFMA pairs 1, 3, 5
+                if constexpr (piece >= 0 && piece <= LDB) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (req_b) issue_b(std::integral_constant<int, piece>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if (req_b) next_b();
+            g2 = ph == 0 ? nB : g1;
+            g1 = (req_b ? nB : 0) + ((req_a && t * NT + wid_s * 64 < P * 4) ? 1 : 0);
+            ++tapoff;
+            if (++tdx == 3) {
+                tdx = 0;
+                tapoff += PW - 3;
+            }
+            if (++t == 9) {
+                t = 0;
+                tapoff = 0;
+                ++ch;
+                ac = ch + 1;                          // the patch pieces requested during chunk ch belong to chunk ch + 1
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");      // every wave is done reading operand slots
+        const long next = tile + tile_step;
+        if (next < ntiles) {
+            init_tile(next);
+            prologue();
+        }
+        int lane_e = lane, wid_e = wid_s;
+        asm volatile("" : "+v"(lane_e), "+s"(wid_e));
+        tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e);
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int EPI = 0>
 static int launch_conv_t(ConvParams p, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
@@ -847,6 +1078,37 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     return IM360_OK;
 }
 
+// the halo kernel's tile geometry, or false when the problem does not fit it (the streaming kernels take it then)
+static bool halo_geometry(ConvParams& p) {
+    if (p.ntaps != 9 || p.stride != 1 || p.up || p.wrap || p.y_off != 0 || p.x_off < 0) return false;
+    if (p.Cout % 320 != 0 || p.Cin % 32 != 0 || p.Cin < 64 || p.Hin != p.Hout) return false;
+    if (p.Wout > 256 || 256 % p.Wout != 0 || p.M % 256 != 0) return false;
+    const int R = 256 / p.Wout;
+    if (!(p.Hout % R == 0 || R % p.Hout == 0)) return false;
+    const int hs = R < p.Hout ? R : p.Hout;
+    const int P = (R / hs) * (hs + 2) * (p.Wout + 2);
+    if (P > 528) return false;
+    p.halo_r = R; p.halo_seg = hs; p.halo_pw = p.Wout + 2; p.halo_p = P;
+    return true;
+}
+
+template <typename T>
+static int launch_halo(ConvParams p, hipStream_t stream) {
+    p.tiles_n = p.Cout / 320;
+    p.nblocks = (p.M / 256) * p.tiles_n;
+    p.dbg = 0;
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n >= 8 ? n / 8 * 8 : 8;
+    }();
+    const long want = (p.nblocks + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(want < ncu ? want : ncu);
+    hipLaunchKernelGGL((conv_halo_kernel<T>), dim3(grid), dim3(512), 0, stream, p);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
 template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     const int big_env = knob(KNOB_CONV_BIG);           // tuning overrides
@@ -854,6 +1116,10 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
     if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
         const bool linear = p.ntaps == 1 && p.Hin == 1 && p.Win == 1 && !p.temb;       // EPI 2 has no temb add
+        if (knob(KNOB_CONV_HALO)) {
+            ConvParams ph = p;
+            if (halo_geometry(ph)) return launch_halo<T>(ph, stream);
+        }
         if (big_env == 2) return linear ? launch_conv_t<T, 2, 2, 2, 5, 2>(p, stream) : launch_conv_t<T, 2, 2, 2, 5>(p, stream);   // A/B: 128 x 320, 2 workgroups per CU
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both

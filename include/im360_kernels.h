@@ -136,7 +136,8 @@ int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64
 
 /* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 allow the 256x320 conv tile,
  * 2 force 32-channel K steps, 3 scalar temporal attention, 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring
- * kernel (asm LDS-DMA), 2 the same with the LDS-DMA builtin).  Defaults are the measured best; the IM360_* environment
+ * kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring
+ * kernel for convolutions too; 6 ablation bits of the ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions).  Defaults are the measured best; the IM360_* environment
  * variables seed them at load time.  None of them changes results. */
 int im360_tuning_set(int knob, int value);
 

@@ -304,6 +304,37 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Win,Cin,Cout,x_off", [(128, 32, 32, 32, 64, 320, 0),      # 8 rows x 32 of one image per tile
+                                                       (512, 16, 16, 16, 96, 320, 0),      # a whole 16 x 16 image per tile
+                                                       (2048, 8, 8, 8, 64, 320, 0),        # four 8 x 8 images per tile
+                                                       (16, 64, 128, 132, 64, 320, 2),     # window of the W+4 tensor, 2 rows per tile
+                                                       (256, 16, 16, 16, 64, 640, 0)])     # two cout tiles
+def test_conv3x3_halo_patch_kernel(dt, N, H, W, Win, Cin, Cout, x_off):
+    """The halo-patch kernel (knob conv_halo): rectangular pixel tiles, the (rows + 2) x (W + 2) input patch of a
+    32-channel chunk in LDS once, nine taps out of it -- against the fp32 reference and against the streaming kernel."""
+    g = torch.Generator().manual_seed(90)
+    x = q16(torch.randn(N, H, Win, Cin, generator=g), dt)
+    w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
+    b = q16(torch.randn(Cout, generator=g) * 0.1, dt)
+    fr = 4
+    temb = q16(torch.randn(N // fr, Cout, generator=g), dt)
+    res = q16(torch.randn(N, H, W, Cout, generator=g), dt)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)[..., x_off:x_off + W].permute(0, 2, 3, 1)
+    ref = (ref + temb.repeat_interleave(fr, 0)[:, None, None, :]).to(dt).float() + res
+    wp = K.pack_conv_weight(w.to(dt).cuda())
+    args = dict(bias=b.to(dt).cuda(), temb=temb.to(dt).cuda(), imgs_per_temb=fr, res=res.to(dt).cuda(), x_off=x_off, wout=W)
+    try:
+        K.tuning_set("conv_halo", 1)
+        out = K.conv2d(x.to(dt).cuda(), wp, Cout, **args)
+        K.tuning_set("conv_halo", 0)
+        old = K.conv2d(x.to(dt).cuda(), wp, Cout, **args)
+    finally:
+        K.tuning_set("conv_halo", 0)
+    assert rel(out, ref) < TOL[dt] and rel(old, ref) < TOL[dt]
+    assert rel(out, old) < (3e-3 if dt == torch.bfloat16 else 4e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_linear_geglu_fused(dt):
     """GEGLU projection + activation in one GEMM launch (interleaved value / gate weight rows) vs Linear -> chunk ->
     a * gelu(gate) in fp32, including a ragged last token tile; and the module-level switch in layers.GEGLU."""
