@@ -35,6 +35,7 @@ def check(name, ours, ref, tol=2e-5):
     r = rel(ours, ref)
     print(f"  oracle-vs-reference {name}: rel {r:.2e}")
     assert r < tol, (name, r)
+    return r
 
 
 def save(name, **arrs):
@@ -254,6 +255,12 @@ def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=N
                latents_dtype=torch.float32, video_batch=vb, use_outpaint=True, use_ip_plus_cross_attention=True,
                use_fps_condition=True, ip_plus_condition="video").videos
     print(f"  reference pipeline {time.time() - t0:.1f}s", vid.shape)
+    if keep is None:
+        out = {f"pano_latent_{i}": t for i, t in enumerate(trace)}
+    else:                   # long runs: a few checkpoints of the latent trajectory, half precision
+        out = {f"pano_latent_{i}": trace[i].half() for i in keep}
+    out["video_sub"] = vid[:, :, ::3, ::4, ::4].half()
+    out["video_frame_stats"] = torch.stack([vid.mean(dim=(0, 1, 3, 4)), vid.std(dim=(0, 1, 3, 4))])
     otrace = []
     torch.manual_seed(21)
     random.seed(21)
@@ -261,9 +268,17 @@ def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=N
     ovid, olat, _ = OP.run(dict(mv.state_dict()), ucfg, dict(vae.state_dict()), vcfg, vb, cond["text_pano"],
                            cond["text_pers"], cond["sam_pano"], cond["sam_pers"], num_inference_steps=steps, trace=otrace)
     print(f"  oracle pipeline {time.time() - t0:.1f}s")
+    # two fp32 evaluations of the same recurrence in different summation orders drift apart under CFG 7.5: the bound
+    # grows with the number of steps (2 steps: 1e-4; 25 steps: a few 1e-4 -- printed, and kept in the fixture)
+    tol = 1e-4 if steps <= 4 else 2e-3
+    drift = []
     for i, (a, b) in enumerate(zip(otrace, trace)):
-        check(f"pipeline latent step {i}", a, b, 1e-4)
-    check("pipeline video", ovid, vid, 1e-4)
+        drift.append(check(f"pipeline latent step {i}", a, b, tol))
+    check("pipeline video", ovid, vid, tol)
+    if keep is not None:
+        out["oracle_vs_reference_rel_l2_per_step"] = torch.tensor([float(d) for d in drift])
+    save(name, **out)
+    return
     if keep is None:
         out = {f"pano_latent_{i}": t for i, t in enumerate(trace)}
     else:                   # long runs: a few checkpoints of the latent trajectory, half precision
