@@ -389,10 +389,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
-    // two query blocks per wave once that still leaves every CU several workgroups
+    // One query block per wave.  Two blocks per wave (knob attn_qb = 2) share each K fragment read; at d = 32 with the bias
+    // that variant needs 256 VGPRs + 180 B of scratch and measures within +-5 % of this one (profiles/r02_kernels.log),
+    // at d = 64 it spills 400-600 B: not used by default.
     const int qb_env = knob(KNOB_ATTN_QB);       // tuning override
-    int qb = (D == 32 && nw == 4 && p.Nq >= 256 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 1024) ? 2 : 1;   // d = 64 spills at QB = 2
-    if (qb_env && nw == 4) qb = qb_env == 2 ? 2 : 1;
+    int qb = 1;
+    if (qb_env == 2 && nw == 4) qb = 2;
     p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);
     const long nblk = (long)p.B * p.H * p.nqt;
     if (nblk > 0x7fffffffL) {

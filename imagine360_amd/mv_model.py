@@ -104,10 +104,12 @@ class WarpAttn(nn.Module):
         h = t.attn1.heads
         a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel)
         a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel)
-        eq = t.attn1.to_out(a_e) + eq
-        eq = t.ff(layer_norm(t.norm2, eq)) + eq
-        pr = t.attn1.to_out(a_p) + pr
-        pr = t.ff(layer_norm(t.norm2, pr)) + pr
+        # residual adds ride in the GEMM epilogues where the token count takes the MFMA kernel (same rounding sequence as
+        # Linear -> + residual; hipBLASLt + add otherwise)
+        eq = t.attn1.out_proj(a_e, residual=eq)
+        eq = t.ff(layer_norm(t.norm2, eq), residual=eq)
+        pr = t.attn1.out_proj(a_p, residual=pr)
+        pr = t.ff(layer_norm(t.norm2, pr), residual=pr)
         pers_out = pr.reshape(b, frames, m, ph, pw, c).permute(0, 2, 1, 3, 4, 5).reshape(nf, ph, pw, c)
         return pers_out.contiguous(), eq.reshape(ne_img, eh, ew, c)
 

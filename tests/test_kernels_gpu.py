@@ -107,6 +107,22 @@ def test_softmax_rows_and_single_head_attention():
         assert rel(out, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_two_query_blocks_per_wave_variant(dt):
+    """The opt-in QB = 2 instantiations (knob attn_qb = 2: one K fragment read feeds two query blocks) stay correct:
+    d = 32 with the shared bias and d = 64, ragged key count."""
+    g = torch.Generator().manual_seed(85)
+    try:
+        K.tuning_set("attn_qb", 2)
+        for H, D, Nq, Nk, has_bias in ((4, 32, 600, 328, True), (2, 64, 512, 200, False)):
+            q, k, v = (q16(torch.randn(2, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
+            bias = q16(torch.rand(Nq, Nk, generator=g) * 2 - 1, dt) if has_bias else None
+            out = K.attention(q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda(), H, bias=None if bias is None else bias.to(dt).cuda())
+            assert rel(out, OU.sdpa(q, k, v, H, bias=bias)) < TOL[dt]
+    finally:
+        K.tuning_set("attn_qb", 0)
+
+
 def test_attention_softmax_rescale_branch():
     """Force the running max to jump in a late KV tile (spiked key) -- the online-softmax rescale path."""
     dt = torch.bfloat16

@@ -50,6 +50,35 @@ def bench_attn(iters):
               f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
 
 
+def bench_attn_variants(iters):
+    """WarpAttn (d = 32 + shared bias): one vs two query blocks per wave; text + IP cross attention: two launches with
+    accumulate vs the single two-set launch."""
+    for name, B, H, Nq, Nk in [("warp L1 e2p", 32, 10, 2048, 5120), ("warp L1 p2e", 32, 10, 5120, 2048), ("warp L2 e2p", 32, 20, 512, 1280)]:
+        D = 32
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        bb = (torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT)
+        fl = 4.0 * B * H * Nq * Nk * D
+        row = []
+        for qb in (1, 2):
+            K.tuning_set("attn_qb", qb)
+            t = timeit(lambda: K.attention(q, k, v, H, bias=bb), iters)
+            row.append(f"QB={qb}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
+        K.tuning_set("attn_qb", 0)
+        print(f"attn  {name:14s} " + " | ".join(row))
+    for name, B, H, Nq, grp in [("pers L0 cross", 640, 5, 1024, 16), ("pano L0 cross", 32, 5, 8192, 16), ("pers L1 cross", 640, 10, 256, 16)]:
+        D = 64
+        q = rn(B, Nq, H * D)
+        k1, v1, k2, v2 = rn(B // grp, 77, H * D), rn(B // grp, 77, H * D), rn(B // grp, 64, H * D), rn(B // grp, 64, H * D)
+
+        def two():
+            o = K.attention(q, k1, v1, H, kv_group=grp)
+            K.attention(q, k2, v2, H, kv_group=grp, out=o, accumulate=True)
+            return o
+        t2 = timeit(two, iters)
+        t1 = timeit(lambda: K.attention2(q, k1, v1, k2, v2, H, kv_group=grp), iters)
+        print(f"attn  {name:14s} two launches {t2 * 1e3:7.3f} ms | one launch (attn_fwd2) {t1 * 1e3:7.3f} ms")
+
+
 def bench_conv(iters):
     shapes = [("pers L0 320->320", 640, 32, 32, 320, 320, False), ("pano L0 320->320 (W+4)", 32, 64, 132, 320, 320, False),
               ("pers L1 640->640", 640, 16, 16, 640, 640, False), ("pers L2 1280->1280", 640, 8, 8, 1280, 1280, False),
