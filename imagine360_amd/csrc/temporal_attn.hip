@@ -11,8 +11,9 @@
 // frames) into LDS with coalesced 16-byte loads, each wave takes (pixel, head) pairs: S^T = K Q^T in
 // ceil(d/32) MFMAs, softmax on the 4 scores a lane holds (+2 cross-lane exchanges), O^T = V^T P^T in ceil(d/16)
 // MFMAs with V gathered by the transposing LDS read, results written over the head's Q slice in LDS and then
-// streamed out as whole token rows.  HBM sees q, k, v, o exactly once.  Longer sequences (frame-sharded 48-frame
-// runs) use the scalar kernel below.
+// streamed out as whole token rows.  HBM sees q, k, v, o exactly once.  17 .. 64 frames (frame-sharded 48-frame runs)
+// run the same scheme on FT x FT tiles (temporal_attn_mfma_long_kernel); the scalar kernel below remains as the
+// fallback for head groups that do not fit 64 KB of LDS and behind the tattn_scalar knob.
 #include <stdlib.h>
 #include "common.h"
 
@@ -199,6 +200,108 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TAttnParams p, 
     }
 }
 
+
+// ---- 17 <= F <= 64 (frame-sharded long clips, BASELINE cfg4): the same scheme on FT x FT tiles of 16 x 16.  One workgroup
+//      stages the FT * 16 frame rows (q | k | v of its head group) of one pixel; the (head, query tile) pairs are dealt to
+//      the four waves; per pair: S^T against all FT key tiles (FT * ceil(d / 32) MFMAs), softmax over the FT * 4 scores a
+//      lane holds (+ 2 exchanges), O^T = sum over key tiles of V^T P^T, parked over the head's Q rows of that query tile.
+template <typename T, int FT>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_long_kernel(TAttnParams p, int hpb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* rows = (T*)smem;                                 // [FT * 16 frames][q_g | k_g | v_g | 8 pad]
+    constexpr int NR = FT * 16;
+    const int F = p.F, d = p.d;
+    const int G = hpb * d;
+    const int pitch = 3 * G + 8;
+    const int h0 = blockIdx.y * hpb;
+    const int tid = threadIdx.x;
+    const long pix = blockIdx.x;
+    const long b = pix / p.P, px = pix % p.P;
+    const int cps = G >> 3;
+    for (int c = tid; c < NR * 3 * cps; c += 256) {
+        const int ch = c % cps, seg = (c / cps) % 3, f = c / (3 * cps);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (f < F) {
+            const T* base = seg == 0 ? (const T*)p.q + b * p.q_bs + px * p.q_ps + (long)f * p.q_fs
+                          : seg == 1 ? (const T*)p.k + b * p.k_bs + px * p.k_ps + (long)f * p.k_fs
+                                     : (const T*)p.v + b * p.v_bs + px * p.v_ps + (long)f * p.v_fs;
+            v = *(const uint4*)(base + h0 * d + ch * 8);
+        }
+        *(uint4*)(rows + f * pitch + seg * G + ch * 8) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int nstep = (d + 31) >> 5, ncb = (d + 15) >> 4;
+    for (int pair = wid; pair < hpb * FT; pair += 4) {
+        const int hl = pair / FT, qi = pair % FT;
+        const T* qrow = rows + (qi * 16 + i16) * pitch + hl * d;
+        // ---- S^T tiles: lane (query qi * 16 + i16, g) gets the scores of keys kt * 16 + 4g .. + 3
+        f32x4 s[FT];
+#pragma unroll
+        for (int kt = 0; kt < FT; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nstep; ++st) {
+            const int k0 = st * 32 + 8 * g;
+            uint4 qf = make_uint4(0u, 0u, 0u, 0u);
+            if (k0 < d) qf = *(const uint4*)(qrow + k0);
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                uint4 kf = make_uint4(0u, 0u, 0u, 0u);
+                if (k0 < d) kf = *(const uint4*)(rows + (kt * 16 + i16) * pitch + G + hl * d + k0);
+                s[kt] = Mfma16<T>::k32(kf, qf, s[kt]);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] = (kt * 16 + 4 * g + r < F) ? s[kt][r] * p.scale_log2 : -INFINITY;
+                m = fmaxf(m, s[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+        u32x2 pf[FT];                                    // P^T per key tile as the B operand
+#pragma unroll
+        for (int kt = 0; kt < FT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m);
+                l += s[kt][r];
+            }
+            pf[kt].x = pack2<T>(s[kt][0], s[kt][1]);
+            pf[kt].y = pack2<T>(s[kt][2], s[kt][3]);
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        // ---- O^T = sum over key tiles of V^T P^T, per 16-channel block
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int c0 = cb * 16;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < FT; ++kt) {
+                const u32x2 vf = lds_read_tr16(rows + (kt * 16 + 4 * g + (i16 >> 2)) * pitch + 2 * G + hl * d + c0 + 4 * (i16 & 3));
+                o = Mfma16<T>::k16(vf, pf[kt], o);
+            }
+            if (c0 + 4 * g < d) {                        // this query tile's Q rows of the head are dead: park the output there
+                uint2 w;
+                w.x = pack2<T>(o[0] * inv, o[1] * inv);
+                w.y = pack2<T>(o[2] * inv, o[3] * inv);
+                *(uint2*)(rows + (qi * 16 + i16) * pitch + hl * d + c0 + 4 * g) = w;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < NR * cps; c += 256) {
+        const int ch = c % cps, f = c / cps;
+        if (f < F)
+            *(uint4*)((T*)p.out + b * p.o_bs + px * p.o_ps + (long)f * p.o_fs + h0 * d + ch * 8) =
+                *(const uint4*)(rows + f * pitch + ch * 8);
+    }
+}
+
 template <typename T, int FMAX>
 static void launch_tattn_v(TAttnParams p, hipStream_t stream) {
     const long npix = p.total / ((long)p.F * p.heads);                 // B * P
@@ -226,6 +329,21 @@ static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
             const long npix = p.total / ((long)p.F * p.heads);
             dim3 grid((unsigned)npix, (unsigned)(p.heads / hpb));
             hipLaunchKernelGGL((temporal_attn_mfma_kernel<T>), grid, dim3(256), lds, stream, p, hpb);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if (p.F > 16 && !scalar_env) {
+        const int ft = (p.F + 15) / 16, nr = ft * 16;
+        int hpb = p.heads;                               // heads per workgroup: nr rows of (3 * hpb * d + 8) elements in <= 64 KB
+        while (hpb > 1 && (hpb % 2) == 0 && (size_t)nr * (3 * hpb * p.d + 8) * sizeof(T) + 64 > 64 * 1024) hpb /= 2;
+        const size_t lds = (size_t)nr * (3 * hpb * p.d + 8) * sizeof(T) + 64;
+        if (lds <= 64 * 1024) {
+            const long npix = p.total / ((long)p.F * p.heads);
+            dim3 grid((unsigned)npix, (unsigned)(p.heads / hpb));
+            if (ft == 2) hipLaunchKernelGGL((temporal_attn_mfma_long_kernel<T, 2>), grid, dim3(256), lds, stream, p, hpb);
+            else if (ft == 3) hipLaunchKernelGGL((temporal_attn_mfma_long_kernel<T, 3>), grid, dim3(256), lds, stream, p, hpb);
+            else hipLaunchKernelGGL((temporal_attn_mfma_long_kernel<T, 4>), grid, dim3(256), lds, stream, p, hpb);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }

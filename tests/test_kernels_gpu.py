@@ -137,7 +137,8 @@ def test_attention_softmax_rescale_branch():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,Fr,P,heads,d", [(2, 16, 96, 8, 40), (3, 8, 33, 8, 8), (1, 48, 20, 8, 16), (2, 16, 7, 8, 160)])
+@pytest.mark.parametrize("B,Fr,P,heads,d", [(2, 16, 96, 8, 40), (3, 8, 33, 8, 8), (1, 48, 20, 8, 16), (2, 16, 7, 8, 160),
+                                            (2, 24, 50, 8, 40), (1, 33, 17, 8, 80), (1, 64, 9, 8, 160), (1, 17, 5, 4, 24)])
 def test_temporal_attention(dt, B, Fr, P, heads, d):
     C = heads * d
     qkv = q16(rnd(B * Fr * P, 3 * C, seed=15), dt)
@@ -146,6 +147,11 @@ def test_temporal_attention(dt, B, Fr, P, heads, d):
     ref = ref.reshape(B, P, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * P, C)
     out = K.temporal_attention(qkv.to(dt).cuda(), B, Fr, P, heads)
     assert rel(out, ref) < TOL[dt]
+    try:                                     # the scalar LDS kernel (fallback / knob) on the same problem
+        K.tuning_set("tattn_scalar", 1)
+        assert rel(K.temporal_attention(qkv.to(dt).cuda(), B, Fr, P, heads), ref) < TOL[dt]
+    finally:
+        K.tuning_set("tattn_scalar", 0)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -96,11 +96,16 @@ def bench_conv(iters):
 
 def bench_temporal(iters):
     for name, B, Fr, P, C in [("pers L0", 40, 16, 1024, 320), ("pano L0", 2, 16, 8192, 320), ("pers L1", 40, 16, 256, 640),
-                              ("pers L2", 40, 16, 64, 1280)]:
+                              ("pers L2", 40, 16, 64, 1280), ("cfg4 pers L0 F48", 40, 48, 256, 320), ("cfg4 pano L0 F48", 2, 48, 2048, 320),
+                              ("cfg4 pers L1 F48", 40, 48, 64, 640)]:
         qkv = rn(B * Fr * P, 3 * C)
         t = timeit(lambda: K.temporal_attention(qkv, B, Fr, P, 8), iters)
         by = 4.0 * B * Fr * P * C * 2
-        print(f"tattn {name:10s} B={B:3d} F={Fr} P={P:5d} C={C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak)")
+        K.tuning_set("tattn_scalar", 1)
+        ts = timeit(lambda: K.temporal_attention(qkv, B, Fr, P, 8), iters)
+        K.tuning_set("tattn_scalar", 0)
+        print(f"tattn {name:16s} B={B:3d} F={Fr} P={P:5d} C={C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak)"
+              f" | scalar kernel {ts * 1e3:8.3f} ms {by / ts / 1e9:7.0f} GB/s")
 
 
 def bench_ln(iters):
