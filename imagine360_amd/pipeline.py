@@ -82,6 +82,7 @@ class AnimationPipeline:
         emb = emb.repeat_interleave(num_videos_per_prompt, dim=0)
         if do_classifier_free_guidance:
             neg = negative_prompt if negative_prompt is not None else [""] * len(prompt)
+            neg = [neg] * len(prompt) if isinstance(neg, str) else ["" if n is None else n for n in neg]   # None -> "" like the reference
             un = self.text_encoder(tok(neg))[0].repeat_interleave(num_videos_per_prompt, dim=0)
             emb = torch.cat([un, emb])
         return emb

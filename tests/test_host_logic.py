@@ -253,3 +253,60 @@ def test_dropin_overlay_runs_the_reference_script():
     u = out["unet_forward"]
     assert u["finite"] and u["ref_missing"] == 0 and u["ref_unexpected"] == 0 and u["rel_vs_reference_forward"] < 5e-5
     assert out["uninstalled"]
+
+
+def test_conditioning_producers_prompt_and_sam_paths():
+    """the pipeline's own conditioning producers (out of the kernel hot path, but part of the kept
+    API): `_encode_prompt` (uncond first, one encode per prompt -- the reference encodes the same prompt once per view,
+    pipeline...dual.py:628,655) and `_sam_features` (uint8 conversion, chunks of 8 frames through a SamPredictor)."""
+    import sys
+    import types
+    import numpy as np
+    from imagine360_amd.pipeline import AnimationPipeline
+
+    calls = {"enc": [], "sam": []}
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, s, **kw):
+            assert kw["padding"] == "max_length" and kw["max_length"] == 77 and kw["truncation"]
+            ids = torch.tensor([[len(x) for _ in range(77)] for x in s])
+            return types.SimpleNamespace(input_ids=ids)
+
+    class Enc(torch.nn.Module):
+        def forward(self, ids):
+            calls["enc"].append(ids.shape)
+            return (ids.float().unsqueeze(-1).expand(-1, -1, 8),)
+
+    class Predictor:
+        class _T:
+            def apply_image(self, im):
+                assert im.dtype == np.uint8 and im.shape[-1] == 3
+                return im
+
+        def __init__(self, model):
+            self.transform = self._T()
+
+        def set_torch_image(self, x, hw):
+            calls["sam"].append(tuple(x.shape))
+            self._n = x.shape[0]
+
+        def get_image_embedding(self):
+            return torch.ones(self._n, 256, 64, 64)
+
+    saved = sys.modules.get("segment_anything")
+    sys.modules["segment_anything"] = types.SimpleNamespace(SamPredictor=Predictor)
+    try:
+        vae = types.SimpleNamespace(config=types.SimpleNamespace(block_out_channels=(1, 2, 3, 4)), device=torch.device("cpu"))
+        pipe = AnimationPipeline(vae, Enc(), Tok(), None, None, None, None, image_encoder=object(), image_encoder_name="SAM")
+        emb = pipe._encode_prompt(["a street at night"], "cpu", 1, True, [None])
+        assert emb.shape == (2, 77, 8) and len(calls["enc"]) == 2            # text + negative, one call each
+        assert emb[0, 0, 0] == 0 and emb[1, 0, 0] == len("a street at night")      # uncond ("" -> length 0) first
+        feats = pipe._sam_features(torch.zeros(1, 16, 3, 32, 32))
+        assert feats.shape == (1, 16, 4096, 256) and calls["sam"] == [(8, 3, 32, 32)] * 2
+    finally:
+        if saved is None:
+            sys.modules.pop("segment_anything", None)
+        else:
+            sys.modules["segment_anything"] = saved
