@@ -47,19 +47,22 @@ def vae_config(width_div=1):
     return cfg
 
 
-def build_unet(width_div=1, device=None):
+def build_unet(width_div=1, device=None, motion_heads=None):
     from .unet3d import UNet3DConditionModel
+    kw = dict(PROMPT_DUAL_UNET_KWARGS)
+    if motion_heads is not None:          # reduced-width test models: keep the temporal head dim a multiple of 8
+        kw["motion_module_kwargs"] = dict(kw["motion_module_kwargs"], num_attention_heads=motion_heads)
     with torch.device(device) if device is not None else _null():
-        return UNet3DConditionModel.from_config(unet_config(width_div), **PROMPT_DUAL_UNET_KWARGS)
+        return UNet3DConditionModel.from_config(unet_config(width_div), **kw)
 
 
-def build_mv_model(width_div=1, device="cuda", dtype=torch.bfloat16, fill=True, xformers=True):
+def build_mv_model(width_div=1, device="cuda", dtype=torch.bfloat16, fill=True, xformers=True, motion_heads=None):
     """Random-init dual-branch model with the deterministic filler weights (no checkpoint is available
     offline).  ``xformers`` mirrors the shipped config's enable_xformers_memory_efficient_attention."""
     from .mv_model import MultiViewBaseModel
     from .weights import fill_module_
     with torch.device(device):
-        mv = MultiViewBaseModel(build_unet(width_div), build_unet(width_div), pano_pad=True)
+        mv = MultiViewBaseModel(build_unet(width_div, motion_heads=motion_heads), build_unet(width_div, motion_heads=motion_heads), pano_pad=True)
     if fill:
         fill_module_(mv)
     mv = mv.to(dtype).eval()

@@ -218,11 +218,12 @@ def gen_mvxf():
     save("mv_forward_w5_xf.npz", pano=o["pano"], pers_views=o["pers_views"])
 
 
-def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=None):
+def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=None, motion_heads=8):
     print("[pipeline]", name)
     R = ref_shims.ref_modules()
     import animatediff.pipelines.pipeline_animation_inference_dual as pipmod
     ucfg, vcfg = sd21_unet_cfg(width_div), sd21_vae_cfg(4)
+    ucfg.motion_heads = motion_heads
     mv = RB.ref_mv(ucfg)
     vae = RB.ref_vae(vcfg)
     vb = S.video_batch(frames=frames, pano_hw=(256, 512), seed=0)
@@ -283,20 +284,13 @@ def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=N
         out["oracle_vs_reference_rel_l2_per_step"] = torch.tensor(drift)
         out["oracle_vs_reference_video_rel_l2"] = torch.tensor(rel(ovid, vid))
     save(name, **out)
-    return
-    if keep is None:
-        out = {f"pano_latent_{i}": t for i, t in enumerate(trace)}
-    else:                   # long runs: a few checkpoints of the latent trajectory, half precision
-        out = {f"pano_latent_{i}": trace[i].half() for i in keep}
-    out["video_sub"] = vid[:, :, ::3, ::4, ::4].half()
-    out["video_frame_stats"] = torch.stack([vid.mean(dim=(0, 1, 3, 4)), vid.std(dim=(0, 1, 3, 4))])
-    save(name, **out)
 
 
 def gen_pipeline25():
-    """The full 25-step DDIM loop (CFG 7.5) of the REAL reference at channels / 10: does the 16-bit error of the MI355X
-    path stay bounded over the recurrence?  (tests/test_model_gpu.py::test_pipeline_25_steps_vs_reference_fixture)"""
-    gen_pipeline(steps=25, frames=16, width_div=10, name="pipeline25_w10.npz", keep=(0, 1, 4, 9, 14, 19, 24))
+    """The full 25-step DDIM loop (CFG 7.5) of the REAL reference at channels / 10, plus how far the fp32 oracle
+    drifts from it per step (the recurrence's own amplification of rounding noise, the yardstick the GPU test uses).  (tests/test_model_gpu.py::test_pipeline_25_steps_vs_reference_fixture)"""
+    # 4 motion-module heads instead of 8: at 32 channels the temporal head dim is then 8, the smallest the kernels take
+    gen_pipeline(steps=25, frames=16, width_div=10, name="pipeline25_w10.npz", keep=(0, 1, 4, 9, 14, 19, 24), motion_heads=4)
 
 
 def gen_keys():

@@ -33,11 +33,13 @@ YAML_UNET_KWARGS = dict(
 
 def ref_unet(cfg: UNetCfg):
     R = ref_shims.ref_modules()
+    kw = dict(YAML_UNET_KWARGS)
+    kw["motion_module_kwargs"] = dict(kw["motion_module_kwargs"], num_attention_heads=cfg.motion_heads)
     return R["UNet3DConditionModel"](
         sample_size=96, in_channels=4, out_channels=4, block_out_channels=tuple(cfg.block_out_channels),
         layers_per_block=cfg.layers_per_block, attention_head_dim=tuple(cfg.attention_head_dim),
         cross_attention_dim=cfg.cross_attention_dim, norm_num_groups=cfg.norm_num_groups,
-        norm_eps=cfg.norm_eps, **YAML_UNET_KWARGS)
+        norm_eps=cfg.norm_eps, **kw)
 
 
 def ref_mv(cfg: UNetCfg):

