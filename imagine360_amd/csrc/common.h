@@ -111,6 +111,24 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x + 0.5f * fabsf(x) * erf_abs;                   // x/2 * (1 + sign(x) erf(|x|/sqrt 2))
 }
 
+// Two exact-GELU values x * Phi(x) at once, for epilogues where the activation is NOT hidden behind HBM (the fused GEGLU
+// GEMM spends a third of its tile time here): erf from Abramowitz & Stegun 7.1.25 (three terms, |error| <= 2.5e-5 in
+// erf, <= 2e-5 relative in GELU for x > 0.05 -- 10x below fp16 output rounding), written on float2 so the plain
+// multiplies / FMAs become v_pk_*_f32 (two lanes-worth per issue slot); only rcp and exp2 stay scalar.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 den = ax * 0.33267250f + 1.0f;                    // 1 + 0.47047 |x| / sqrt 2
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 pl = t * 0.7478556f + (-0.0958798f);
+    pl = pl * t + 0.3480242f;
+    const f32x2 q = pl * t;
+    const f32x2 w = (x * x) * (-0.72134752f);                     // -x^2 / 2 in log2 units
+    const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
+    const f32x2 erf_abs = 1.0f - q * e;                           // erf(|x| / sqrt 2)
+    return (ax * 0.5f) * erf_abs + x * 0.5f;                      // x/2 * (1 + sign(x) erf(|x| / sqrt 2))
+}
+
 // compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>), for bodies that need the index as
 // a constant expression (register arrays, immediate LDS offsets)
 template <int N, typename F>

@@ -73,6 +73,19 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
         const T* gb = bias ? bias : (const T*)g_zero_chunk;      // unconditional bias loads (see the plain epilogue)
         const int gbmul = bias ? 1 : 0;
+        // the biases of this lane's channels, unpacked once for all TM pixel blocks (the K-loop operand registers are free)
+        f32x2 bv[TN / 2][4][2], bt[TN / 2][4][2];
+#pragma unroll
+        for (int i = 0; i < TN / 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;          // packed rows (bias index)
+                const uint2 wv = *(const uint2*)(gb + rv * gbmul), wg = *(const uint2*)(gb + rg * gbmul);
+                bv[i][g][0] = f32x2{unpack_lo<T>(wv.x), unpack_hi<T>(wv.x)};
+                bv[i][g][1] = f32x2{unpack_lo<T>(wv.y), unpack_hi<T>(wv.y)};
+                bt[i][g][0] = f32x2{unpack_lo<T>(wg.x), unpack_hi<T>(wg.x)};
+                bt[i][g][1] = f32x2{unpack_lo<T>(wg.y), unpack_hi<T>(wg.y)};
+            }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const long mb = m0 + wm * (TM * 32) + b * 32;
@@ -80,24 +93,19 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             for (int i = 0; i < TN / 2; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows (bias index)
-                    float v[4], t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = acc[2 * i][b][4 * g + j]; t[j] = acc[2 * i + 1][b][4 * g + j]; }
-                    {
-                        const uint2 wv = *(const uint2*)(gb + rv * gbmul), wg = *(const uint2*)(gb + rg * gbmul);
-                        v[0] += unpack_lo<T>(wv.x); v[1] += unpack_hi<T>(wv.x); v[2] += unpack_lo<T>(wv.y); v[3] += unpack_hi<T>(wv.y);
-                        t[0] += unpack_lo<T>(wg.x); t[1] += unpack_hi<T>(wg.x); t[2] += unpack_lo<T>(wg.y); t[3] += unpack_hi<T>(wg.y);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // the unfused path rounds the projection to 16 bits before the activation: keep that rounding
-                        const float vr = to_f32(from_f32<T>(v[j])), tr = to_f32(from_f32<T>(t[j]));
-                        v[j] = vr * gelu_erf_fast(tr);
-                    }
+                    // (the unfused path rounds the projection to 16 bits before the activation; this one does not --
+                    //  one rounding less on the way to the fp32 oracle)
+                    f32x2 v01 = {acc[2 * i][b][4 * g], acc[2 * i][b][4 * g + 1]}, v23 = {acc[2 * i][b][4 * g + 2], acc[2 * i][b][4 * g + 3]};
+                    f32x2 t01 = {acc[2 * i + 1][b][4 * g], acc[2 * i + 1][b][4 * g + 1]}, t23 = {acc[2 * i + 1][b][4 * g + 2], acc[2 * i + 1][b][4 * g + 3]};
+                    v01 += bv[i][g][0];
+                    v23 += bv[i][g][1];
+                    t01 += bt[i][g][0];
+                    t23 += bt[i][g][1];
+                    v01 *= gelu_erf_pk(t01);
+                    v23 *= gelu_erf_pk(t23);
                     uint2 o;
-                    o.x = pack2<T>(v[0], v[1]);
-                    o.y = pack2<T>(v[2], v[3]);
+                    o.x = pack2<T>(v01.x, v01.y);
+                    o.y = pack2<T>(v23.x, v23.y);
                     *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1044,8 +1052,8 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         return IM360_ERR_ARG;
     }
     const int bk_env = knob(KNOB_CONV_BK);       // tuning override
-    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && EPI != 1;      // the 8-wave tiles are BK = 64 only
-    if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN == 5)) || !has_bk32) {      // (the 128 x 320 tile exists for two workgroups per CU: 32-channel stages)
+    constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && (EPI != 1 || NT == 256);      // the 8-wave GEGLU tile is BK = 64 only
+    if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1202,6 +1210,10 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     IM360_CHECK_ARG(M <= 0x7fffffffL, "linear_geglu: M too large");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
+    if (knob(KNOB_CONV_BIG) == 3) {            // A/B: 128 x 256 tiles, two 4-wave workgroups per CU (one's GELU epilogue under the other's K loop)
+        if (dtype == 0) return launch_conv_t<__bf16, 2, 2, 2, 4, 1>(p, s);
+        if (dtype == 1) return launch_conv_t<_Float16, 2, 2, 2, 4, 1>(p, s);
+    }
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
         const int v = knob(KNOB_CONV_RING) >= 5 ? 1 : knob(KNOB_CONV_RING);
         if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);

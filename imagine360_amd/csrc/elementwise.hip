@@ -12,71 +12,89 @@
 
 namespace im360 {
 
-// one wave per token row; row values stay in registers between the two statistics passes
-template <typename T, int MAXCH>
+// one wave per ROWS consecutive token rows; row values stay in registers between the two statistics passes.  ROWS > 1
+// for narrow rows: a 320-channel row is one 16-byte load on 40 of the 64 lanes, and one such load per wave in flight
+// (32 waves x 640 B = 20 KB per CU) does not cover the HBM latency; all ROWS x MAXCH loads are issued before any use.
+template <typename T, int MAXCH, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
                                                          const T* __restrict__ beta, const T* __restrict__ pre,
                                                          const T* __restrict__ post, T* __restrict__ y, long rows, int C,
                                                          long pre_period, long post_div, long post_mod, float eps) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= rows) return;
     const int nch = C >> 3;
-    const T* xr = x + row * C;
-    const T* pr = pre ? pre + (row % pre_period) * C : nullptr;
-    float v[MAXCH][8];
-    float sum = 0.f;
+    uint4 raw[ROWS][MAXCH], rawp[ROWS][MAXCH];
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < nch) {
-            unpack8<T>(*(const uint4*)(xr + ch * 8), v[k]);
-            if (pr) {
-                float a[8];
-                unpack8<T>(*(const uint4*)(pr + ch * 8), a);
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1;           // tail rows re-read the last row, never stored
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[k][e] += a[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[k][e];
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < nch) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = v[k][e] - mean;
-                sq += d * d;
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                raw[r][k] = *(const uint4*)(x + row * C + ch * 8);
+                if (pre) rawp[r][k] = *(const uint4*)(pre + (row % pre_period) * C + ch * 8);
             }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = rsqrtf(sq / (float)C + eps);
-    const T* po = post ? post + ((row / post_div) % post_mod) * C : nullptr;
-    T* yr = y + row * C;
+    for (int r = 0; r < ROWS; ++r) {
+        const long row = row0 + r;
+        float v[MAXCH][8];
+        float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-        const int ch = lane + k * 64;
-        if (ch < nch) {
-            float g[8], b[8], o[8];
-            unpack8<T>(*(const uint4*)(gamma + ch * 8), g);
-            unpack8<T>(*(const uint4*)(beta + ch * 8), b);
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                unpack8<T>(raw[r][k], v[k]);
+                if (pre) {
+                    float a[8];
+                    unpack8<T>(rawp[r][k], a);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
-            if (po) {
-                float a[8];
-                unpack8<T>(*(const uint4*)(po + ch * 8), a);
+                    for (int e = 0; e < 8; ++e) v[k][e] += a[e];
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += a[e];
+                for (int e = 0; e < 8; ++e) sum += v[k][e];
             }
-            *(uint4*)(yr + ch * 8) = pack8<T>(o);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[k][e] - mean;
+                    sq += d * d;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = rsqrtf(sq / (float)C + eps);
+        if (row >= rows) continue;                                          // wave-uniform
+        const T* po = post ? post + ((row / post_div) % post_mod) * C : nullptr;
+        T* yr = y + row * C;
+#pragma unroll
+        for (int k = 0; k < MAXCH; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                float g[8], b[8], o[8];
+                unpack8<T>(*(const uint4*)(gamma + ch * 8), g);
+                unpack8<T>(*(const uint4*)(beta + ch * 8), b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+                if (po) {
+                    float a[8];
+                    unpack8<T>(*(const uint4*)(po + ch * 8), a);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += a[e];
+                }
+                *(uint4*)(yr + ch * 8) = pack8<T>(o);
+            }
         }
     }
 }
@@ -101,16 +119,15 @@ __global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long 
 template <typename T>
 static int launch_ln(const void* x, const void* gamma, const void* beta, const void* pre, const void* post, void* y,
                      long rows, int C, long pre_period, long post_div, long post_mod, float eps, hipStream_t s) {
-    const unsigned blocks = (unsigned)((rows + 3) / 4);
     const int nch = C / 8;
-#define IM360_LN(MC)                                                                                              \
-    hipLaunchKernelGGL((layernorm_kernel<T, MC>), dim3(blocks), dim3(256), 0, s, (const T*)x, (const T*)gamma,    \
-                       (const T*)beta, (const T*)pre, (const T*)post, (T*)y, rows, C, pre_period, post_div,       \
-                       post_mod, eps)
-    if (nch <= 64) IM360_LN(1);
-    else if (nch <= 128) IM360_LN(2);
-    else if (nch <= 192) IM360_LN(3);
-    else IM360_LN(4);
+#define IM360_LN(MC, R)                                                                                           \
+    hipLaunchKernelGGL((layernorm_kernel<T, MC, R>), dim3((unsigned)((rows + 4 * R - 1) / (4 * R))), dim3(256), 0, \
+                       s, (const T*)x, (const T*)gamma, (const T*)beta, (const T*)pre, (const T*)post, (T*)y,     \
+                       rows, C, pre_period, post_div, post_mod, eps)
+    if (nch <= 64) IM360_LN(1, 4);
+    else if (nch <= 128) IM360_LN(2, 2);
+    else if (nch <= 192) IM360_LN(3, 1);
+    else IM360_LN(4, 1);
 #undef IM360_LN
     IM360_CHECK_LAUNCH();
     return IM360_OK;

@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         if (pl < lanes) {
-            for (int pix = pix0 + pl; pix < pix1; pix += lanes) {
+            const T* xc = xb + (c0 + cc) * 8;
+            auto add = [&](const uint4& raw, int pix) {
                 float f[8];
-                unpack8<T>(*(const uint4*)(xb + (long)pix * C + (c0 + cc) * 8), f);
+                unpack8<T>(raw, f);
                 float wgt = 1.f;
                 if (pad > 0) {
                     const int xx = pix % W;
@@ -48,7 +49,21 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
                     acc[e] += wgt * f[e];
                     acc[8 + e] += wgt * f[e] * f[e];
                 }
+            };
+            // four independent 16-byte loads in flight per thread: one is not enough to cover the HBM latency
+            // (8 workgroups x 256 threads x 16 B = 32 KB per CU in flight gave ~3.5 TB/s)
+            int pix = pix0 + pl;
+            for (; pix + 3 * lanes < pix1; pix += 4 * lanes) {
+                const uint4 r0 = *(const uint4*)(xc + (long)pix * C);
+                const uint4 r1 = *(const uint4*)(xc + (long)(pix + lanes) * C);
+                const uint4 r2 = *(const uint4*)(xc + (long)(pix + 2 * lanes) * C);
+                const uint4 r3 = *(const uint4*)(xc + (long)(pix + 3 * lanes) * C);
+                add(r0, pix);
+                add(r1, pix + lanes);
+                add(r2, pix + 2 * lanes);
+                add(r3, pix + 3 * lanes);
             }
+            for (; pix < pix1; pix += lanes) add(*(const uint4*)(xc + (long)pix * C), pix);
         }
         __syncthreads();
 #pragma unroll
@@ -131,20 +146,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             sc[e] = sp[e];
             sh[e] = hp[e];
         }
-        for (int pix = pix0 + pl; pix < pix1; pix += lanes) {
+        const T* xc = xb + (c0 + cc) * 8;
+        T* yc = yb + (c0 + cc) * 8;
+        auto src = [&](int pix) {
             int sx = pix % Wo - pad;
             const int sy = pix / Wo;
             if (sx < 0) sx += W;
             else if (sx >= W) sx -= W;
+            return *(const uint4*)(xc + ((long)sy * W + sx) * C);
+        };
+        auto emit = [&](const uint4& raw, int pix) {
             float f[8];
-            unpack8<T>(*(const uint4*)(xb + ((long)sy * W + sx) * C + (c0 + cc) * 8), f);
+            unpack8<T>(raw, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = f[e] * sc[e] + sh[e];
                 f[e] = act ? silu_f(v) : v;
             }
-            *(uint4*)(yb + (long)pix * C + (c0 + cc) * 8) = pack8<T>(f);
+            *(uint4*)(yc + (long)pix * C) = pack8<T>(f);
+        };
+        int pix = pix0 + pl;                       // four loads in flight per thread (see gn_partial_kernel)
+        for (; pix + 3 * lanes < pix1; pix += 4 * lanes) {
+            const uint4 r0 = src(pix), r1 = src(pix + lanes), r2 = src(pix + 2 * lanes), r3 = src(pix + 3 * lanes);
+            emit(r0, pix);
+            emit(r1, pix + lanes);
+            emit(r2, pix + 2 * lanes);
+            emit(r3, pix + 3 * lanes);
         }
+        for (; pix < pix1; pix += lanes) emit(src(pix), pix);
     }
 }
 

@@ -15,7 +15,7 @@ from imagine360_amd import kernels as K  # noqa: E402
 
 DT = torch.bfloat16
 DEV = "cuda"
-VARIANTS = [0, 1, -7]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
+VARIANTS = [0, 1, -3]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
 
 
 def rn(*s, scale=1.0):
@@ -39,7 +39,7 @@ def run_variants(name, fn, flops, bytes_, iters, check):
     outs, times = [], []
     for v in VARIANTS:
         K.tuning_set("conv_ring", 1 if v == -7 else max(v, 0))
-        K.tuning_set("conv_big", 2 if v == -2 else 1)
+        K.tuning_set("conv_big", 2 if v == -2 else 3 if v == -3 else 1)
         K.tuning_set("conv_halo", 1 if v == -7 else 0)
         if check:
             outs.append(fn().clone())
