@@ -194,6 +194,29 @@ __global__ void circular_pad_w_kernel(const T* __restrict__ x, T* __restrict__ y
     }
 }
 
+// ---- circular pad of the last two axes of a W-last tensor (torch.nn.functional.pad(x, (l, r, t, b), "circular")):
+//      the 360-degree close-loop patch of the super-resolution stage (sr/video_to_video_model.py:16-29, 99, 160-162 via
+//      src/utils/pano.py:75-101) and any NCHW pad_pano.  Works on units of U bytes (the host picks the widest U in
+//      {16, 8, 4, 2} that divides the row, both W pads and the pointers), one unit per thread, rows x units grid-stride.
+template <typename U>
+__global__ void circular_pad_hw_kernel(const U* __restrict__ x, U* __restrict__ y, long N, int H, int W, int left,
+                                       int right, int top, int bottom) {
+    const int Wo = W + left + right, Ho = H + top + bottom;
+    const long total = N * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo);
+        const long t = i / Wo;
+        const int yo = (int)(t % Ho);
+        const long n = t / Ho;
+        int sx = xo - left, sy = yo - top;
+        if (sx < 0) sx += W;
+        else if (sx >= W) sx -= W;
+        if (sy < 0) sy += H;
+        else if (sy >= H) sy -= H;
+        y[i] = x[(n * H + sy) * W + sx];
+    }
+}
+
 // ---- CFG combine + DDIM v-prediction update (eta = 0), one elementwise pass
 //      (pipeline_animation_inference_dual.py:791-800; diffusers/schedulers/scheduling_ddim.py:300-350):
 //      v = u + g (c - u);  x_prev = cx * x + cv * v   with cx, cv precomputed on the host in fp64
@@ -306,6 +329,36 @@ extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_
     // a byte copy of 16-bit elements: one instantiation serves both dtypes
     hipLaunchKernelGGL((circular_pad_w_kernel<uint16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (uint16_t*)y, (long)rows, (int)W, (int)(C / 8), (int)pad);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// x [N, H, W] -> y [N, H + top + bottom, W + left + right], circular in both axes; elements of `esize` bytes (1, 2, 4, 8).
+// Each pad must not exceed the size of its axis (torch's rule for mode="circular").
+extern "C" int im360_circular_pad_hw(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t left, int64_t right,
+                                     int64_t top, int64_t bottom, int64_t esize, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && y, "circular_pad_hw: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0, "circular_pad_hw: empty tensor");
+    IM360_CHECK_ARG(esize == 1 || esize == 2 || esize == 4 || esize == 8, "circular_pad_hw: element size %ld unsupported", (long)esize);
+    IM360_CHECK_ARG(left >= 0 && right >= 0 && top >= 0 && bottom >= 0 && left <= W && right <= W && top <= H && bottom <= H,
+                    "circular_pad_hw: pads (%ld, %ld, %ld, %ld) must lie in [0, size of the axis]", (long)left, (long)right, (long)top, (long)bottom);
+    IM360_CHECK_ARG((W + left + right) * esize <= 0x7fffffffL && H + top + bottom <= 0x7fffffffL, "circular_pad_hw: row too long");
+    const long wb = W * esize, lb = left * esize, rb = right * esize;
+    const uintptr_t align = (uintptr_t)x | (uintptr_t)y | (uintptr_t)wb | (uintptr_t)lb | (uintptr_t)rb;
+    const int u = (align % 16) == 0 ? 16 : (align % 8) == 0 ? 8 : (align % 4) == 0 ? 4 : (align % 2) == 0 ? 2 : 1;
+    const long units = N * (H + top + bottom) * ((wb + lb + rb) / u);
+    const unsigned blocks = (unsigned)((units + 255) / 256 > 16384 ? 16384 : (units + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+#define IM360_PAD(U)                                                                                             \
+    hipLaunchKernelGGL((circular_pad_hw_kernel<U>), dim3(blocks), dim3(256), 0, s, (const U*)x, (U*)y, (long)N,   \
+                       (int)H, (int)(wb / u), (int)(lb / u), (int)(rb / u), (int)top, (int)bottom)
+    if (u == 16) IM360_PAD(uint4);
+    else if (u == 8) IM360_PAD(uint2);
+    else if (u == 4) IM360_PAD(uint32_t);
+    else if (u == 2) IM360_PAD(uint16_t);
+    else IM360_PAD(uint8_t);
+#undef IM360_PAD
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
+    "im360_circular_pad_hw": (_INT, [_PTR] * 2 + [_I64] * 8 + [_PTR]),
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR, _PTR]),
     "im360_layernorm": (_INT, [_PTR] * 6 + [_I64] * 5 + [_F32, _INT, _PTR]),
     "im360_geglu": (_INT, [_PTR] * 2 + [_I64] * 2 + [_INT, _PTR]),
@@ -355,6 +356,19 @@ def circular_pad_w(x, pad):
     y = torch.empty(x.shape[:-2] + (W + 2 * pad, C), dtype=x.dtype, device=x.device)
     rc = lib().im360_circular_pad_w(_p(x), _p(y), rows, W, C, pad, _dt(x), _stream())
     _check(rc, "im360_circular_pad_w")
+    return y
+
+
+def circular_pad_hw(x, left, right, top=0, bottom=0):
+    """``F.pad(x, (left, right, top, bottom), mode="circular")`` on the last two axes of a contiguous W-last tensor of
+    any dtype (one HBM pass)."""
+    _dev(x)
+    assert x.is_contiguous() and x.dim() >= 2
+    H, W = x.shape[-2], x.shape[-1]
+    n = x.numel() // (H * W)
+    y = torch.empty(x.shape[:-2] + (H + top + bottom, W + left + right), dtype=x.dtype, device=x.device)
+    rc = lib().im360_circular_pad_hw(_p(x), _p(y), n, H, W, left, right, top, bottom, x.element_size(), _stream())
+    _check(rc, "im360_circular_pad_hw")
     return y
 
 

@@ -99,6 +99,13 @@ int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, 
 int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
                          int dtype, void* stream);
 
+/* x [N, H, W] (W last, elements of esize = 1 / 2 / 4 / 8 bytes) -> y [N, H + top + bottom, W + left + right], circular in
+ * both axes = torch.nn.functional.pad(x, (left, right, top, bottom), mode="circular"); each pad <= the size of its axis.
+ * Replaces: the 360-degree close-loop patch of the super-resolution stage -- padding_pano / pad_pano on NCHW video and
+ *   latent tensors and the circular pad_to_fit, sr/video_to_video_model.py:16-29, 99, 160-162; src/utils/pano.py:75-95. */
+int im360_circular_pad_hw(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t left, int64_t right,
+                          int64_t top, int64_t bottom, int64_t esize, void* stream);
+
 /* out = cx * x + cv * (uncond + guidance * (cond - uncond)); cx, cv = DDIM v-prediction coefficients;
  * coef_dev (optional): device float[3] = (guidance, cx, cv) overriding the scalars (hipGraph replay).
  * Replaces: the CFG combine + DDIMScheduler.step elementwise chain,

@@ -24,6 +24,33 @@ def unpad_pano(x, p):
     return x if p <= 0 else x[..., p:-p]
 
 
+def padding_pano(pano, padding=16, latent=False):
+    """The SR stage's close-loop pad (sr/video_to_video_model.py:21-24): ``padding`` counts latent columns, pixel-space
+    tensors get 8x as many; 4- or 5-dim W-last tensors only, as the reference's pad_pano (src/utils/pano.py:79-86)."""
+    if not latent:
+        padding *= 8
+    if padding > 0 and pano.ndim not in (4, 5):
+        raise NotImplementedError("pano should be 4 or 5 dim")
+    return pad_pano(pano, padding)
+
+
+def unpadding_pano(pano_pad, padding=16, latent=False):
+    """sr/video_to_video_model.py:26-29."""
+    if not latent:
+        padding *= 8
+    return unpad_pano(pano_pad, padding)
+
+
+def circular_pad(x, pad):
+    """``F.pad(x, (w1, w2, h1, h2), "circular")`` of the SR stage's pad_to_fit replacement (sr/video_to_video_model.py:99),
+    restated with index arithmetic: out[..., i, j] = x[..., (i - h1) mod H, (j - w1) mod W]."""
+    w1, w2, h1, h2 = pad
+    H, W = x.shape[-2], x.shape[-1]
+    iy = (torch.arange(H + h1 + h2) - h1) % H
+    ix = (torch.arange(W + w1 + w2) - w1) % W
+    return x[..., iy, :][..., ix]
+
+
 def rodrigues(v):
     """Axis-angle -> rotation matrix (cv2.Rodrigues restated: I + sin(t) K + (1-cos t) K^2)."""
     v = np.asarray(v, dtype=np.float64).reshape(3)

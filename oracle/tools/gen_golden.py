@@ -15,6 +15,7 @@ import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ref_build as RB  # noqa: E402
@@ -291,6 +292,29 @@ def gen_pipeline25():
     drifts from it per step (the recurrence's own amplification of rounding noise, the yardstick the GPU test uses).  (tests/test_model_gpu.py::test_pipeline_25_steps_vs_reference_fixture)"""
     # 4 motion-module heads instead of 8: at 32 channels the temporal head dim is then 8, the smallest the kernels take
     gen_pipeline(steps=25, frames=16, width_div=10, name="pipeline25_w10.npz", keep=(0, 1, 4, 9, 14, 19, 24), motion_heads=4)
+
+
+def gen_srpad():
+    """SR close-loop patch: the REAL src/utils/pano.py pad_pano / unpad_pano as sr/video_to_video_model.py
+    calls them (16 latent columns, x 8 in pixel space), and torch's circular F.pad of :99.  The sr module itself cannot be
+    imported (VEnhancer's video_to_video package is not in the checkout); its two four-line helpers are restated in the
+    oracle and pinned here through the functions they call."""
+    print("[srpad]")
+    ref_shims.ref_modules()
+    from src.utils.pano import pad_pano as ref_pad, unpad_pano as ref_unpad
+    g = torch.Generator().manual_seed(77)
+    lat = torch.randn(1, 4, 3, 8, 40, generator=g).half()               # (b c f h w) latent of a 64 x 320 video
+    vid = torch.randn(1, 3, 2, 16, 256, generator=g)                      # decoded frames, pixel space (fp32)
+    fr = torch.randn(3, 3, 10, 24, generator=g)                            # (f c h w) input frames of :99
+    out = {"lat": lat, "vid": vid, "fr": fr,
+           "lat_pad16": ref_pad(lat, 16), "vid_pad128": ref_pad(vid, 128), "vid_unpad128": ref_unpad(ref_pad(vid, 128), 128).contiguous(),
+           "fr_fit": F.pad(fr, (3, 5, 2, 4), "circular")}
+    assert torch.equal(OG.padding_pano(lat, 16, latent=True), out["lat_pad16"])             # copies: bit-exact
+    assert torch.equal(OG.padding_pano(vid, 16, latent=False), out["vid_pad128"])
+    assert torch.equal(OG.unpadding_pano(out["vid_pad128"], 16, latent=False), vid)
+    assert torch.equal(OG.circular_pad(fr, (3, 5, 2, 4)), out["fr_fit"])
+    print("  oracle == reference (bit-exact)")
+    save("sr_pad.npz", **out)
 
 
 def gen_keys():

@@ -119,6 +119,12 @@ def circular_pad_w(x, pad):
     return torch.cat([x[..., -pad:, :], x, x[..., :pad, :]], dim=-2).contiguous()
 
 
+def circular_pad_hw(x, left, right, top=0, bottom=0):
+    H, W = x.shape[-2], x.shape[-1]
+    y = F.pad(x.reshape(1, -1, H, W), (left, right, top, bottom), mode="circular")
+    return y.reshape(x.shape[:-2] + y.shape[-2:]).contiguous()
+
+
 def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
     if coef_dev is not None:
         guidance, cx, cv = (float(x) for x in coef_dev)
@@ -159,7 +165,7 @@ def linear_geglu(x, w, b, inner):
 
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
-          "conv2d", "circular_pad_w", "cfg_ddim_update", "softmax_rows", "attention2"]
+          "conv2d", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2"]
 
 
 @contextlib.contextmanager

@@ -310,3 +310,29 @@ def test_conditioning_producers_prompt_and_sam_paths():
             sys.modules.pop("segment_anything", None)
         else:
             sys.modules["segment_anything"] = saved
+
+
+def test_sr_patch_module_mirrors_the_reference_helpers():
+    """imagine360_amd.sr_patch on the torch stand-in of the pad kernel: names, argument meaning, identity
+    for padding 0, view semantics of the unpad and the NotImplementedError of the reference for other ranks."""
+    import numpy as np
+    import os
+    from helpers import GOLDEN
+    from imagine360_amd import sr_patch
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "sr_pad.npz")).items()}
+    with E.patched_kernels():
+        import imagine360_amd.kernels as K
+        saved, K._dev = K._dev, lambda *a: None
+        try:
+            assert torch.equal(sr_patch.padding_pano(g["lat"], latent=True), g["lat_pad16"])
+            assert torch.equal(sr_patch.padding_pano(g["vid"]), g["vid_pad128"])
+            assert torch.equal(sr_patch.circular_pad(g["fr"], (3, 5, 2, 4)), g["fr_fit"])
+        finally:
+            K._dev = saved
+    un = sr_patch.unpadding_pano(g["vid_pad128"])
+    assert torch.equal(un, g["vid"]) and un.data_ptr() != g["vid"].data_ptr() and not un.is_contiguous()       # a slice, like the reference
+    assert sr_patch.padding_pano(g["lat"], padding=0, latent=True) is g["lat"]
+    with pytest.raises(NotImplementedError):
+        sr_patch.padding_pano(g["lat"][0, 0, 0], latent=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sr_patch.padding_pano(g["lat"], latent=True)                 # the product path needs the HIP extension

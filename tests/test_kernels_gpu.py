@@ -251,10 +251,10 @@ def test_conv3x3_256x320_tiles(dt, N, H, W, Cin, Cout, wrap):
     assert rel(out, ref) < TOL[dt]
 
 
-def test_conv3x3_256x320_tiles_addressing_modes():
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv3x3_256x320_tiles_addressing_modes(dt):
     """The stride-2 / nearest-upsample / pre-padded-window addressing modes at pixel counts that take the 8-wave
     256 x 320 tile (the cfg2 Downsample3D / Upsample3D / pano conv2 launches), against the reference composition."""
-    dt = torch.bfloat16
     C, Co = 64, 320
     w = q16(rnd(Co, C, 3, 3, seed=71, scale=(9 * C) ** -0.5), dt)
     b = q16(rnd(Co, seed=72, scale=0.1), dt)
@@ -388,6 +388,45 @@ def test_circular_pad_and_cfg_ddim():
     ref = cx * s + cv * (u + g * (c - u))
     out = K.cfg_ddim_update(u.to(dt).cuda(), c.to(dt).cuda(), s.to(dt).cuda(), g, cx, cv)
     assert rel(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32, torch.uint8, torch.float64])
+def test_sr_close_loop_circular_pad(dt):
+    """SURVEY row N4 (sr/video_to_video_model.py:16-29, 99, 160-162): im360_circular_pad_hw against the reference fixture,
+    the oracle and torch's own circular pad, bit-exact, for every unit width the launcher can pick (16 / 8 / 4 / 2 / 1
+    bytes: odd widths and pads), both axes, pads equal to the axis size, and the module API."""
+    import numpy as np
+    import os
+    from helpers import GOLDEN
+    from imagine360_amd import sr_patch
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "sr_pad.npz")).items()}
+    if dt == torch.float16:
+        assert torch.equal(sr_patch.padding_pano(g["lat"].cuda(), latent=True).cpu(), g["lat_pad16"])
+    if dt == torch.float32:
+        vp = sr_patch.padding_pano(g["vid"].cuda())
+        assert torch.equal(vp.cpu(), g["vid_pad128"])
+        assert torch.equal(sr_patch.unpadding_pano(vp).cpu(), g["vid"])
+        assert torch.equal(sr_patch.circular_pad(g["fr"].cuda(), (3, 5, 2, 4)).cpu(), g["fr_fit"])
+    gen = torch.Generator().manual_seed(5)
+    for shape, pad in [((2, 3, 4, 16, 64), (16, 16, 0, 0)), ((1, 3, 9, 31), (5, 2, 3, 1)), ((3, 7, 13), (13, 13, 7, 7)),
+                       ((2, 2, 6, 24), (8, 0, 0, 6)), ((1, 1, 5, 33), (1, 0, 0, 0))]:
+        x = torch.randint(0, 255, shape, generator=gen).to(dt) if dt == torch.uint8 else torch.randn(shape, generator=gen).to(dt)
+        ref = OG.circular_pad(x, pad)
+        got = K.circular_pad_hw(x.cuda(), *pad).cpu()
+        assert got.shape == ref.shape and torch.equal(got.view(torch.uint8), ref.contiguous().view(torch.uint8)), (shape, pad)
+    with pytest.raises(RuntimeError, match="pads"):
+        K.circular_pad_hw(torch.zeros(1, 4, 8, device="cuda"), 9, 0)
+
+
+def test_sr_close_loop_pad_full_size_round_trip():
+    """At the SR stage's real size (2x upscaled 1024 x 2048 frames, fp16): pad 128 columns -> the wrap columns equal the
+    opposite border, unpad returns the input bit-exactly (size-independent property; no reference at this size)."""
+    from imagine360_amd import sr_patch
+    x = torch.randn(1, 3, 8, 1024, 2048, device="cuda").half()
+    y = sr_patch.padding_pano(x)
+    assert y.shape[-1] == 2048 + 256
+    assert torch.equal(y[..., :128], x[..., -128:]) and torch.equal(y[..., -128:], x[..., :128])
+    assert torch.equal(sr_patch.unpadding_pano(y), x)
 
 
 def test_bad_arguments_fail_loudly():

@@ -118,3 +118,19 @@ def test_pipeline_against_reference(mv_sd, vae_sd):
         assert rel(t, g[f"pano_latent_{i}"]) < 1e-4
     assert rel(vid[:, :, ::3, ::4, ::4], g["video_sub"]) < 1e-3          # fixture stored as fp16
     assert vid.min() >= 0 and vid.max() <= 1 and vid.shape == (1, 3, 16, 256, 512)
+
+
+def test_sr_close_loop_pad_against_reference():
+    """the oracle's padding_pano / unpadding_pano / circular_pad == the real src/utils/pano.py pad_pano /
+    unpad_pano as sr/video_to_video_model.py:16-29, 99, 160-162 calls them (tests/golden/sr_pad.npz), bit-exact."""
+    import numpy as np
+    import os
+    from helpers import GOLDEN
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "sr_pad.npz")).items()}     # keep fp16 / fp32 as stored
+    assert torch.equal(OG.padding_pano(g["lat"], 16, latent=True), g["lat_pad16"])
+    assert torch.equal(OG.padding_pano(g["vid"], 16, latent=False), g["vid_pad128"])
+    assert torch.equal(OG.unpadding_pano(g["vid_pad128"], 16, latent=False), g["vid_unpad128"])
+    assert torch.equal(OG.circular_pad(g["fr"], (3, 5, 2, 4)), g["fr_fit"])
+    assert OG.padding_pano(g["lat"], 0, latent=True) is g["lat"]
+    with pytest.raises(NotImplementedError):
+        OG.padding_pano(g["lat"][0, 0, 0], 16, latent=True)

@@ -133,6 +133,21 @@ def bench_gn(iters):
               f"{2 * by / t2 / 1e9:6.0f} GB/s")
 
 
+def bench_srpad(iters):
+    """SR close-loop pad: algorithmic bytes = output read once + written once."""
+    from imagine360_amd import sr_patch
+    for name, shape, dt, latent in [("SR video 1024x2048 fp16", (1, 3, 16, 1024, 2048), torch.float16, False),
+                                    ("SR video 1024x2048 fp32", (1, 3, 16, 1024, 2048), torch.float32, False),
+                                    ("SR latent 128x256 fp16", (1, 4, 32, 128, 256), torch.float16, True)]:
+        x = torch.randn(shape, device="cuda").to(dt)
+        t = timeit(lambda: sr_patch.padding_pano(x, latent=latent), iters)
+        y = sr_patch.padding_pano(x, latent=latent)
+        by = 2.0 * y.numel() * y.element_size()
+        pw = (y.shape[-1] - x.shape[-1]) // 2
+        tt = timeit(lambda: torch.nn.functional.pad(x.flatten(0, 2), [pw, pw], mode="circular"), iters)      # what pad_pano does
+        print(f"srpad {name:26s}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak) | torch F.pad circular {tt * 1e3:8.3f} ms")
+
+
 def bench_linear(iters):
     """torch F.linear (hipBLASLt) vs the implicit-GEMM kernel used as a 1x1 conv on the same shapes."""
     import torch.nn.functional as F
