@@ -268,7 +268,11 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // The 128-wide tiles move 1 byte of operands into LDS per 64 flops and saturate the CU's global->LDS path at ~30 % of
 // the MFMA peak (same throughput at 2 or 3 resident workgroups); the 256 x 320 tile halves the bytes per flop
 // (142 flop/B) and runs as one 8-wave workgroup per CU (144 KB of LDS for the two stages).
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0>
+// CM ("chunk-major", 3x3 without wrap / upsample only): K runs over (64-channel chunk, tap) instead of (tap, chunk).  The nine
+// shifted reads of one chunk then follow each other, so eight of them hit the XCD's L2 (the tap-major order re-streams the
+// pixel tile from the fabric for every tap: fetch / input = 8.9 - 14, profiles/r02_hbm_traffic.json).  The fp32 summation
+// order differs from the tap-major kernels.
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -361,12 +365,56 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
             amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
         }
     };
-    set_tap(0);
+    // chunk-major state: the centre pixel's pointer per slot, nine validity bits per slot, and wave-uniform element offsets
+    // of the current tap (relative to the centre) and of the current channel chunk
+    uint32_t vmask[LDA];
+    long tapdelta = 0, kofs = 0;
+    if constexpr (CM) {
+#pragma unroll
+        for (int i = 0; i < LDA; ++i) {
+            const int cy = (int)(pyx[i] & 0xffffu) * p.stride + p.y_off, cx = (int)(pyx[i] >> 16) * p.stride + p.x_off;
+            uint32_t m = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int gy = cy + t / 3 - 1, gx = cx + t % 3 - 1;
+                m |= (gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) ? (1u << t) : 0u;
+            }
+            const bool valid = (pnv[i] >> 31) != 0;
+            vmask[i] = valid ? m : 0u;
+            aptr[i] = valid ? xg + (((long)(pnv[i] & 0x7fffffffu) * p.Hin + cy) * p.Win + cx) * p.Cin + pd8 : xg;
+        }
+        tapdelta = -(long)(p.Win + 1) * p.Cin;          // tap 0 = (dy, dx) = (-1, -1)
+    } else {
+        set_tap(0);
+    }
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
 
     auto stage = [&](int buf) {
         char* abase = lds + buf * STAGE + wid_s * 1024;
         char* bbase = abase + TILE_A;
+        if constexpr (CM) {
+            const long aoff = tapdelta + kofs, boff = (long)tap_p * p.Cin + kofs;
+#pragma unroll
+            for (int i = 0; i < LDA; ++i) {
+                const T* src = ((vmask[i] >> tap_p) & 1u) ? aptr[i] + aoff : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(abase + i * (NT * 16)), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < LDB; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr + i * bstride + boff),
+                                                 (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
+            }
+            ++tap_p;
+            tapdelta += p.Cin;
+            if (tap_p == 3 || tap_p == 6) tapdelta += (long)(p.Win - 3) * p.Cin;
+            if (tap_p == 9) {
+                tap_p = 0;
+                tapdelta = -(long)(p.Win + 1) * p.Cin;
+                kofs += BK;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < LDA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
@@ -1053,7 +1101,13 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     }
     const int bk_env = knob(KNOB_CONV_BK);       // tuning override
     constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && (EPI != 1 || NT == 256);      // the 8-wave GEGLU tile is BK = 64 only
-    if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
+    // 3x3 convolutions without wrap / upsample addressing: taps innermost (see the kernel); the 256 x 320 and 128 x 128 tiles
+    constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2));
+    const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
+    if (cm) {
+        if constexpr (has_cm)
+            hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+    } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);

@@ -141,11 +141,13 @@ int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_pac
 int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
                        float scale, int dtype, void* stream);
 
-/* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 allow the 256x320 conv tile,
- * 2 force 32-channel K steps, 3 scalar temporal attention, 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring
- * kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring
- * kernel for convolutions too; 6 ablation bits of the ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions).  Defaults are the measured best; the IM360_* environment
- * variables seed them at load time.  None of them changes results. */
+/* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 conv tile policy: 0 never the
+ * 256x320 tile, 2 / 3 two-workgroup 128x320 / 128x256 tiles, 2 force 32-channel K steps, 3 scalar temporal attention,
+ * 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring
+ * (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring kernel for convolutions too; 5 reserved; 6 ablation bits of the
+ * ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions; 8 taps-innermost K order of the 3x3 convolutions
+ * (default 1)).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * change the fp32 summation order, 6 breaks results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);
 
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,

@@ -309,12 +309,14 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
     temb, cres = torch.randn(29, 320, generator=g).to(dt).cuda(), torch.randn(145, 30, 31, 320, generator=g).to(dt).cuda()
     outs = {}
     try:
+        K.tuning_set("conv_cm", 0)          # the ring kernel sums taps outermost: compare it with the tap-major two-stage kernel
         for v in (0, 1, 3, 4, 5):
             K.tuning_set("conv_ring", v)
             outs[v] = (K.conv2d(x, wp, N, bias=b, res=r), K.linear_geglu(gx, gwp, gbp, 256),
                        K.conv2d(cx, cwp, 320, bias=b, temb=temb, imgs_per_temb=5, res=cres))
     finally:
         K.tuning_set("conv_ring", 1)
+        K.tuning_set("conv_cm", 1)
     for v in (1, 3, 4, 5):
         for a, ref in zip(outs[v], outs[0]):
             assert torch.equal(a, ref), v
@@ -323,6 +325,40 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
     conv_ref = (F.conv2d(cx.float().permute(0, 3, 1, 2), cw.float(), b.float(), padding=1).permute(0, 2, 3, 1)
                 + temb.float().repeat_interleave(5, 0)[:, None, None, :]).to(dt).float() + cres.float()
     assert rel(outs[5][2], conv_ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,kw", [(640, 32, 32, 128, 320, dict()),                       # 256 x 320 tiles
+                                               (32, 64, 132, 64, 320, dict(x_off=2, wout=128)),       # window of the W+4 tensor
+                                               (320, 32, 32, 64, 320, dict(stride=2)),                # stride 2 (uniform tap offsets too)
+                                               (145, 30, 31, 192, 96, dict()),                        # ragged, 128 x 128 tiles
+                                               (3, 5, 7, 64, 64, dict())])                            # images smaller than a tile
+def test_conv3x3_chunk_major_k_order(dt, N, H, W, Cin, Cout, kw):
+    """Taps-innermost K order (knob conv_cm, default for 3x3 convs without wrap / upsample addressing: eight of the nine
+    shifted reads of a channel chunk hit L2) against the tap-major order and the fp32 reference, with bias, time embedding
+    and residual; the two orders differ only in fp32 summation order."""
+    g = torch.Generator().manual_seed(91)
+    x = q16(torch.randn(N, H, W, Cin, generator=g), dt)
+    w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
+    b = q16(torch.randn(Cout, generator=g) * 0.1, dt)
+    stride, x_off, wout = kw.get("stride", 1), kw.get("x_off", 0), kw.get("wout", W)
+    xr = x.permute(0, 3, 1, 2)
+    if x_off:
+        ref = F.conv2d(xr, w, b, padding=1)[..., x_off:x_off + wout].permute(0, 2, 3, 1)
+    else:
+        ref = F.conv2d(xr, w, b, padding=1, stride=stride).permute(0, 2, 3, 1)
+    res = q16(torch.randn(ref.shape, generator=g), dt)
+    ref = q16(ref, dt) + res
+    wp = K.pack_conv_weight(w.to(dt).cuda())
+    outs = []
+    try:
+        for cm in (1, 0):
+            K.tuning_set("conv_cm", cm)
+            outs.append(K.conv2d(x.to(dt).cuda(), wp, Cout, bias=b.to(dt).cuda(), res=res.to(dt).cuda(), **kw))
+    finally:
+        K.tuning_set("conv_cm", 1)
+    assert rel(outs[0], ref) < TOL[dt] and rel(outs[1], ref) < TOL[dt]
+    assert rel(outs[0], outs[1].float().cpu()) < TOL[dt] / 4
 
 
 @pytest.mark.parametrize("dt", DTYPES)

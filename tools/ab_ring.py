@@ -15,7 +15,7 @@ from imagine360_amd import kernels as K  # noqa: E402
 
 DT = torch.bfloat16
 DEV = "cuda"
-VARIANTS = [0, 1, -3]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
+VARIANTS = [0, -8, 1]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
 
 
 def rn(*s, scale=1.0):
@@ -41,12 +41,14 @@ def run_variants(name, fn, flops, bytes_, iters, check):
         K.tuning_set("conv_ring", 1 if v == -7 else max(v, 0))
         K.tuning_set("conv_big", 2 if v == -2 else 3 if v == -3 else 1)
         K.tuning_set("conv_halo", 1 if v == -7 else 0)
+        K.tuning_set("conv_cm", 0 if v == -8 else 1)       # -8: two-stage kernel, tap-major K order (round-2 start)
         if check:
             outs.append(fn().clone())
         times.append(timeit(fn, iters))
     K.tuning_set("conv_ring", 1)
     K.tuning_set("conv_big", 1)
     K.tuning_set("conv_halo", 0)
+    K.tuning_set("conv_cm", 1)
     same = ""
     if check:
         same = " identical" if all(torch.equal(outs[0], o) for o in outs[1:]) else " max|diff| " + " ".join(
