@@ -43,6 +43,11 @@ struct ConvParams {
 // 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
 __device__ uint4 g_zero_chunk[1];
 
+// keep a value alive without code (ablation switches of the ring kernel; a __device__ helper because the host pass of
+// hipcc silently drops a __global__ body whose inline asm it cannot type for x86)
+__device__ __forceinline__ void keep_alive(u32x4 v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v)); }
+
 // ---- epilogue shared by the tile kernels.  `lds` is a region of at least (waves * 32 * row bytes) that no wave reads
 //      as operand tiles any more; the caller has passed a workgroup barrier since the last operand read.
 template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false>
@@ -272,7 +277,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // shifted reads of one chunk then follow each other, so eight of them hit the XCD's L2 (the tap-major order re-streams the
 // pixel tile from the fabric for every tap: fetch / input = 8.9 - 14, profiles/r02_hbm_traffic.json).  The fp32 summation
 // order differs from the tap-major kernels.
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false>
+// ABL: ablation build (knob conv_dbg, tools/ab_ring.py --ablate): bit 1 of p.dbg skips the LDS-DMA of the K loop, bit 2 the MFMAs.
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
     stage(0);
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
-        if (s + 1 < nsteps) stage((s + 1) & 1);
+        if (s + 1 < nsteps && !(ABL && (p.dbg & 1))) stage((s + 1) & 1);
         const char* at = lds + (s & 1) * STAGE;
         const char* bt = at + TILE_A;
         // software-pipelined fragment reads: the pixel fragments and the first TN - LATE weight fragments of K chunk
@@ -467,6 +473,14 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
             for (int a = 0; a < LATE; ++a) wl[a] = *(const u32x4*)(bt + wrow + koff[kc] + (TN - LATE + a) * (32 * ROWB));
             if constexpr (kc + 1 < KC) fetch(std::integral_constant<int, kc + 1>{});
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this chunk's MFMAs (hipcc sinks it otherwise)
+            if (ABL && (p.dbg & 2)) {
+#pragma unroll
+                for (int a = 0; a < TN - LATE; ++a) keep_alive(wf[kc & 1][a]);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) keep_alive(xf[kc & 1][b]);
+#pragma unroll
+                for (int a = 0; a < LATE; ++a) keep_alive(wl[a]);
+            } else
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -496,10 +510,6 @@ __device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst
                  : "memory");
 }
 
-// keep a value alive without code (ablation switches of the ring kernel; a __device__ helper because the host pass of
-// hipcc silently drops a __global__ body whose inline asm it cannot type for x86)
-__device__ __forceinline__ void keep_alive(u32x4 v) { asm volatile("" ::"v"(v)); }
-__device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v)); }
 
 // ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
 // The kernel above keeps two LDS stages of 64 channels and drains the LDS-DMA queue at every step (one barrier per step,
@@ -1104,6 +1114,15 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     // 3x3 convolutions without wrap / upsample addressing: taps innermost (see the kernel); the 256 x 320 and 128 x 128 tiles
     constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2));
     const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
+    p.dbg = knob(KNOB_CONV_DBG);
+    if constexpr (WM == 4 && WN == 2 && TN == 5 && EPI == 0) {
+        if (p.dbg && p.Cin % 64 == 0) {         // ablation build of the 256 x 320 conv tile (results are garbage)
+            if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
     if (cm) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);

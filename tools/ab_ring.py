@@ -72,6 +72,18 @@ def ablate(iters):
     cases.append(("conv pers L0 320>320", lambda: K.conv2d(x3, w3, 320, bias=b)))
     x4, w4 = rn(640, 16, 16, 640), K.pack_conv_weight(rn(640, 640, 3, 3, scale=5760 ** -0.5))
     cases.append(("conv pers L1 640>640", lambda: K.conv2d(x4, w4, 640)))
+    # the two-stage kernel (the default for convolutions), taps innermost (conv_cm 1, default) and tap-major
+    for cm in (1, 0):
+        K.tuning_set("conv_ring", 0)
+        K.tuning_set("conv_cm", cm)
+        for name, fn in cases[2:]:
+            row = []
+            for dbg, lab in [(0, "full"), (1, "noDMA"), (2, "noMFMA"), (3, "noDMA+noMFMA")]:
+                K.tuning_set("conv_dbg", dbg)
+                row.append(f"{lab}={timeit(fn, iters):.3f}")
+            K.tuning_set("conv_dbg", 0)
+            print(f"two-stage cm={cm} {name:28s} " + " ".join(row), flush=True)
+    K.tuning_set("conv_cm", 1)
     K.tuning_set("conv_ring", 3)
     for name, fn in cases:
         row = []
