@@ -279,7 +279,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // order differs from the tap-major kernels.
 // ABL: ablation build (knob conv_dbg, tools/ab_ring.py --ablate): bit 1 of p.dbg skips the LDS-DMA of the K loop, bit 2 the MFMAs.
 template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN * 16 > 200 ? 1 : 2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -395,22 +395,28 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
     }
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
 
-    auto stage = [&](int buf) {
+    // one LDS-DMA piece (1 KiB per wave) of the next K step: pieces 0 .. LDA-1 are the pixel rows, LDA .. LDA+LDB-1 the weights;
+    // the producer state only moves in stage_advance(), so the pieces of a step can be issued anywhere inside the step
+    auto stage_piece = [&](int buf, auto jc) {
+        constexpr int j = decltype(jc)::value;
         char* abase = lds + buf * STAGE + wid_s * 1024;
         char* bbase = abase + TILE_A;
+        if constexpr (j < LDA) {
+            const T* src;
+            if constexpr (CM) src = ((vmask[j] >> tap_p) & 1u) ? aptr[j] + (tapdelta + kofs) : zero;
+            else src = aptr[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(abase + j * (NT * 16)), 16, 0, 0);
+        } else {
+            constexpr int i = j - LDA;
+            const T* src = bptr + i * bstride;
+            if constexpr (CM) src += (long)tap_p * p.Cin + kofs;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
+        }
+    };
+    auto stage_advance = [&]() {
         if constexpr (CM) {
-            const long aoff = tapdelta + kofs, boff = (long)tap_p * p.Cin + kofs;
-#pragma unroll
-            for (int i = 0; i < LDA; ++i) {
-                const T* src = ((vmask[i] >> tap_p) & 1u) ? aptr[i] + aoff : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(abase + i * (NT * 16)), 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < LDB; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr + i * bstride + boff),
-                                                 (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
-            }
             ++tap_p;
             tapdelta += p.Cin;
             if (tap_p == 3 || tap_p == 6) tapdelta += (long)(p.Win - 3) * p.Cin;
@@ -419,25 +425,24 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
                 tapdelta = -(long)(p.Win + 1) * p.Cin;
                 kofs += BK;
             }
-            return;
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < LDA; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)aptr[i],
-                                             (__attribute__((address_space(3))) void*)(abase + i * (NT * 16)), 16, 0, 0);
-            aptr[i] += ((amask >> i) & 1u) ? BK : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < LDB; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bptr + i * bstride),
-                                             (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
-        }
-        bptr += BK;
-        if (++kk_p == ksteps_per_tap) {
-            kk_p = 0;
-            if (++tap_p < p.ntaps) set_tap(tap_p);
+            for (int i = 0; i < LDA; ++i) aptr[i] += ((amask >> i) & 1u) ? BK : 0;
+            bptr += BK;
+            if (++kk_p == ksteps_per_tap) {
+                kk_p = 0;
+                if (++tap_p < p.ntaps) set_tap(tap_p);
+            }
         }
     };
+    auto stage = [&](int buf) {
+        static_for<LDA + LDB>([&](auto jc) { stage_piece(buf, jc); });
+        stage_advance();
+    };
+    // One wave per SIMD (the 4-wave 192 x 320 tile): nobody else fills the matrix pipe while this wave issues its 16 pieces
+    // back to back, so they are spread over the step's MFMAs instead, PPC pieces per 16-channel chunk.
+    constexpr bool ILV = NT == 256 && TM * TN * 16 > 200;
+    constexpr int PPC = (LDA + LDB + KC - 1) / KC;
 
     // fragment byte offsets inside a tile: row R, K chunk d -> R * ROWB + ((d ^ swz(R)) * 16).  Every row a lane reads
     // is its base row + a multiple of 32, and swz only looks at row bits below 32, so the swizzled chunk offset is one
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
     stage(0);
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
-        if (s + 1 < nsteps && !(ABL && (p.dbg & 1))) stage((s + 1) & 1);
+        const bool more = s + 1 < nsteps && !(ABL && (p.dbg & 1));
+        if (!ILV && more) stage((s + 1) & 1);
         const char* at = lds + (s & 1) * STAGE;
         const char* bt = at + TILE_A;
         // software-pipelined fragment reads: the pixel fragments and the first TN - LATE weight fragments of K chunk
@@ -480,6 +486,22 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
                 for (int b = 0; b < TM; ++b) keep_alive(xf[kc & 1][b]);
 #pragma unroll
                 for (int a = 0; a < LATE; ++a) keep_alive(wl[a]);
+            } else if constexpr (ILV) {
+                // MFMAs of this chunk with the chunk's share of the next step's pieces pinned between them
+                constexpr int NM = TN * TM, GAP = NM / PPC;
+                static_for<NM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, a = m / TM, b = m % TM;
+                    acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, a < TN - LATE ? wf[kc & 1][a < TN - LATE ? a : 0] : wl[a >= TN - LATE ? a - (TN - LATE) : 0]),
+                                                __builtin_bit_cast(uint4, xf[kc & 1][b]), acc[a][b]);
+                    if constexpr ((m + 1) % GAP == 0 && (m + 1) / GAP <= PPC) {
+                        constexpr int j = kc * PPC + (m + 1) / GAP - 1;
+                        if constexpr (j < LDA + LDB) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) stage_piece((s + 1) & 1, std::integral_constant<int, j>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                });
             } else
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -489,6 +511,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(2)
                                                 __builtin_bit_cast(uint4, xf[kc & 1][b]), acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (ILV && more) stage_advance();
     }
 
     static_assert((NT / 64) * 32 * (EPI == 1 ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
@@ -1112,10 +1135,10 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     const int bk_env = knob(KNOB_CONV_BK);       // tuning override
     constexpr bool has_bk32 = (BN * 4) % NT == 0 && (BM * 4) % NT == 0 && (EPI != 1 || NT == 256);      // the 8-wave GEGLU tile is BK = 64 only
     // 3x3 convolutions without wrap / upsample addressing: taps innermost (see the kernel); the 256 x 320 and 128 x 128 tiles
-    constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2));
+    constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 3 && TN == 5));
     const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
     p.dbg = knob(KNOB_CONV_DBG);
-    if constexpr (WM == 4 && WN == 2 && TN == 5 && EPI == 0) {
+    if constexpr (((WM == 4 && WN == 2) || (WM == 2 && WN == 2 && TM == 3)) && TN == 5 && EPI == 0) {
         if (p.dbg && p.Cin % 64 == 0) {         // ablation build of the 256 x 320 conv tile (results are garbage)
             if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
             else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1126,7 +1149,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     if (cm) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
-    } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
+    } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4 && TM == 2)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1202,6 +1225,9 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
             if (halo_geometry(ph)) return launch_halo<T>(ph, stream);
         }
         if (big_env == 2) return linear ? launch_conv_t<T, 2, 2, 2, 5, 2>(p, stream) : launch_conv_t<T, 2, 2, 2, 5>(p, stream);   // A/B: 128 x 320, 2 workgroups per CU
+        // A/B: the same 256 x 320 tile on FOUR waves (128 x 160 each, 320 accumulators in the unified 512-register file, one
+        // wave per SIMD): 144 instead of 224 KB of fragment reads per K step
+        if (big_env == 4 && !linear) return launch_conv_t<T, 2, 2, 3, 5>(p, stream);
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
         if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env);

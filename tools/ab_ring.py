@@ -15,7 +15,7 @@ from imagine360_amd import kernels as K  # noqa: E402
 
 DT = torch.bfloat16
 DEV = "cuda"
-VARIANTS = [0, -8, 1]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
+VARIANTS = [0, -4]          # conv_ring values; -2 = two-stage kernel on 128 x 320 tiles; -7 = halo-patch conv kernel (conv_ring 1)
 
 
 def rn(*s, scale=1.0):
@@ -39,7 +39,7 @@ def run_variants(name, fn, flops, bytes_, iters, check):
     outs, times = [], []
     for v in VARIANTS:
         K.tuning_set("conv_ring", 1 if v == -7 else max(v, 0))
-        K.tuning_set("conv_big", 2 if v == -2 else 3 if v == -3 else 1)
+        K.tuning_set("conv_big", 2 if v == -2 else 3 if v == -3 else 4 if v == -4 else 1)
         K.tuning_set("conv_halo", 1 if v == -7 else 0)
         K.tuning_set("conv_cm", 0 if v == -8 else 1)       # -8: two-stage kernel, tap-major K order (round-2 start)
         if check:
@@ -73,17 +73,19 @@ def ablate(iters):
     x4, w4 = rn(640, 16, 16, 640), K.pack_conv_weight(rn(640, 640, 3, 3, scale=5760 ** -0.5))
     cases.append(("conv pers L1 640>640", lambda: K.conv2d(x4, w4, 640)))
     # the two-stage kernel (the default for convolutions), taps innermost (conv_cm 1, default) and tap-major
-    for cm in (1, 0):
+    for cm, big in ((1, 1), (0, 1), (1, 4)):            # big 4: the same tile on four waves (192 x 320, one wave per SIMD)
         K.tuning_set("conv_ring", 0)
         K.tuning_set("conv_cm", cm)
+        K.tuning_set("conv_big", big)
         for name, fn in cases[2:]:
             row = []
             for dbg, lab in [(0, "full"), (1, "noDMA"), (2, "noMFMA"), (3, "noDMA+noMFMA")]:
                 K.tuning_set("conv_dbg", dbg)
                 row.append(f"{lab}={timeit(fn, iters):.3f}")
             K.tuning_set("conv_dbg", 0)
-            print(f"two-stage cm={cm} {name:28s} " + " ".join(row), flush=True)
+            print(f"two-stage cm={cm} big={big} {name:28s} " + " ".join(row), flush=True)
     K.tuning_set("conv_cm", 1)
+    K.tuning_set("conv_big", 1)
     K.tuning_set("conv_ring", 3)
     for name, fn in cases:
         row = []
