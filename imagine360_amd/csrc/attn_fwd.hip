@@ -316,12 +316,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         load_tile(0);
         store_tile(0);
         if (ntiles > 1) load_tile(1);
-        for (int t = 0; t < ntiles; ++t) {
+        // a ragged last tile is peeled out of the loop: with both bodies inside it hipcc gave them different registers and
+        // copied the output accumulators and the max block twice per tile (68 moves, a quarter of the loop's VALU work)
+        const int nfull = ragged ? ntiles - 1 : ntiles;
+        for (int t = 0; t < nfull; ++t) {
             __syncthreads();                 // tile t is visible; every wave is done with tile t-1 (buffer (t+1)&1)
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
             if (t + 2 < ntiles) load_tile(t + 2);      // in flight during the whole compute phase below
-            if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
-            else tile_body(t, std::false_type{});
+            tile_body(t, std::false_type{});
+        }
+        if (ragged) {
+            __syncthreads();
+            tile_body(ntiles - 1, std::true_type{});
         }
     };
     run_set();
@@ -389,12 +395,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
-    // One query block per wave.  Two blocks per wave (knob attn_qb = 2) share each K fragment read; at d = 32 with the bias
-    // that variant needs 256 VGPRs + 180 B of scratch and measures within +-5 % of this one (profiles/r02_kernels.log),
-    // at d = 64 it spills 400-600 B: not used by default.
+    // Query blocks per wave.  Two blocks share each K fragment read and halve the K/V staging per query.  Measured
+    // (tools/bench_kernels.py attn_variants): WarpAttn level 1 (d = 32 + bias, 222 VGPRs, no scratch) 1.62 vs 1.87 ms,
+    // panorama level-0 self-attention (d = 64, 48 B of scratch) 2.75 vs 3.10 ms = 1.0 PF/s, perspective level 0 1.09 vs
+    // 1.19 ms; a tie on small grids, where one block per wave keeps more workgroups in flight.  Knob attn_qb: 0 = this
+    // rule, 1 / 2 = force.
     const int qb_env = knob(KNOB_ATTN_QB);       // tuning override
     int qb = 1;
-    if (qb_env == 2 && nw == 4) qb = 2;
+    if (nw == 4 && (qb_env == 2 || (qb_env == 0 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 1024))) qb = 2;
     p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);
     const long nblk = (long)p.B * p.H * p.nqt;
     if (nblk > 0x7fffffffL) {

@@ -65,6 +65,17 @@ def bench_attn_variants(iters):
             row.append(f"QB={qb}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
         K.tuning_set("attn_qb", 0)
         print(f"attn  {name:14s} " + " | ".join(row))
+    for name, B, H, Nq, Nk in [("pano L0 self d64", 32, 5, 8192, 8192), ("pers L0 self d64", 640, 5, 1024, 1024)]:
+        D = 64
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        fl = 4.0 * B * H * Nq * Nk * D
+        row = []
+        for qb in (1, 2):
+            K.tuning_set("attn_qb", qb)
+            t = timeit(lambda: K.attention(q, k, v, H), iters)
+            row.append(f"QB={qb}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
+        K.tuning_set("attn_qb", 0)
+        print(f"attn  {name:14s} " + " | ".join(row))
     for name, B, H, Nq, grp in [("pers L0 cross", 640, 5, 1024, 16), ("pano L0 cross", 32, 5, 8192, 16), ("pers L1 cross", 640, 10, 256, 16)]:
         D = 64
         q = rn(B, Nq, H * D)
