@@ -37,6 +37,7 @@ struct AttnParams {
     float scale_log2;    // logit scale * log2(e)
     float out_scale;     // multiplies the normalised result
     int accumulate;      // out += result instead of out = result
+    int bias_packed;     // bias / bias_alt are fp16 matrices pre-multiplied by log2(e) (im360_attn_pack_bias)
     // optional SECOND key/value set of the same queries (DUAL kernels): out = out_scale * attn(q, k, v) + out_scale2 *
     // attn(q, k2, v2), two independent softmaxes -- the text + IP-adapter cross attention in ONE launch
     const void* k2; const void* v2;
@@ -49,9 +50,14 @@ constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between rescales
 
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false>
+// BF ("bias fragments"): the bias matrices hold fp16 values already multiplied by log2(e) (im360_attn_pack_bias) and enter
+// the scores through the matrix pipe -- two f16 MFMAs per 32 x 32 score block with a 32 x 16 slice of the identity as the
+// A operand and 16 bytes of a bias row as the B operand -- instead of 16 unpack + 16 FMA VALU instructions per lane and
+// block.  WarpAttn (d = 32) does half the MFMA work of d = 64 per score on the same softmax VALU work and is VALU-bound.
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
+    static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
     constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
     constexpr int VP = D == 64 ? 96 : 32;   // V tile pitch: 192-B / 64-B rows -> rows r..r+3 hit 4 distinct 64-B bank windows
@@ -124,6 +130,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         l_run[qb] = 0.f;
     }
 
+    // BF: identity slices I[32 keys][16 c .. 16 c + 15] as f16 A operands: lane (row, hi) holds I[row][16 c + 8 hi .. + 7]
+    uint4 idA[2];
+    if constexpr (BF) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t = col - 16 * c - 8 * hi;                  // position of the 1.0 inside this lane's 8 halves, if any
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (t == 2 * j) ? 0x00003C00u : (t == 2 * j + 1) ? 0x3C000000u : 0u;
+            idA[c] = uint4{w[0], w[1], w[2], w[3]};
+        }
+    }
+
     int ntiles = (set_nk + KVB - 1) / KVB;
     bool ragged = (set_nk % KVB) != 0;          // the last tile is partial: clamp its rows, mask its scores
     u32x4 kreg[CLD], vreg[CLD];
@@ -179,10 +198,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int kv0 = t * KVB;
 
         // bias words first (per tile at QB = 1, per half otherwise): their L2 latency hides under the QK^T MFMAs
-        uint2 bw[HAS_BIAS ? QB : 1][2][4];
+        uint2 bw[HAS_BIAS && !BF ? QB : 1][2][4];
+        uint4 bfm[BF ? QB : 1][2][2];          // BF: [query block][half][16-key chunk]: keys 16 c + 8 hi .. + 7 of the lane's query row
         auto load_bias = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            if (HAS_BIAS) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int key0 = min(kv0 + kb * 32 + 16 * c + 8 * hi, set_nk - 8);     // Nk % 8 == 0 (checked on the host)
+                        bfm[qb][QK_ALL ? kb : 0][c] = *(const uint4*)(bias + (long)qrow[qb] * p.bias_rs + key0);
+                    }
+            } else if (HAS_BIAS) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -206,6 +234,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
                     s[qb][kb] = Elem<T>::mfma32(a, qf[qb][dc], dc == 0 ? negm[qb] : s[qb][kb]);
             }
+            if constexpr (BF) {
+#pragma unroll
+                for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) s[qb][kb] = Elem<_Float16>::mfma32(idA[c], bfm[qb][QK_ALL ? kb : 0][c], s[qb][kb]);
+            }
         };
         // online-softmax update of block qb over the halves [K0, K1), then O^T += V^T P^T for them
         auto softmax_pv = [&](auto qbc, auto k0c, auto k1c) {
@@ -213,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
             for (int kb = K0; kb < K1; ++kb) {
                 f32x16& sv = s[qb][kb];
-                if (HAS_BIAS) {
+                if (HAS_BIAS && !BF) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint2 w = bw[qb][QK_ALL ? kb : 0][g];
@@ -298,6 +332,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const uint4 a = *(const uint4*)(kf + kb * 32 * KP + dc * 16);
                     s[0][kb] = Elem<T>::mfma32(a, qf[0][dc], dc == 0 ? negm[0] : s[0][kb]);
                 }
+            if constexpr (BF) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) s[0][kb] = Elem<_Float16>::mfma32(idA[c], bfm[0][kb][c], s[0][kb]);
+            }
             softmax_pv(I0{}, I0{}, I2{});
         } else {
             static_for<2>([&](auto kbc) {
@@ -410,6 +450,20 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
         return IM360_ERR_ARG;
     }
     dim3 grid((unsigned)nblk, 1, 1);
+    if constexpr (HAS_BIAS && D == 32) {
+        if (p.bias_packed) {
+            if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, true, false, true>), grid, dim3(64), 0, stream, p);
+            else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
+            else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if (p.bias_packed) {
+        im360_set_error("attn_fwd: packed bias matrices are supported for head dim 32 only");
+        return IM360_ERR_UNSUPPORTED;
+    }
     if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
     else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
     else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS>), grid, dim3(256), 0, stream, p);
@@ -464,10 +518,15 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
                     "attn_fwd: strides must keep 16-byte (q,k,v) / 8-byte (out) alignment");
     IM360_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                     ((uintptr_t)out % 8) == 0, "attn_fwd: misaligned base pointer");
+    const int bias_packed = (dtype & 0x100) ? 1 : 0;       // dtype + 256: packed fp16 bias matrices (see the header)
+    dtype &= 0xff;
     if (bias) {
         IM360_CHECK_ARG((Nk % 4) == 0 && Nk >= 4 && (bias_rs % 4) == 0 && ((uintptr_t)bias % 8) == 0,
                         "attn_fwd: bias needs Nk %% 4 == 0 and 8-byte aligned rows");
+        IM360_CHECK_ARG(!bias_packed || ((Nk % 8) == 0 && (bias_rs % 8) == 0 && ((uintptr_t)bias % 16) == 0 && ((uintptr_t)bias_alt % 16) == 0),
+                        "attn_fwd: packed bias needs Nk %% 8 == 0 and 16-byte aligned rows");
     }
+    IM360_CHECK_ARG(bias || !bias_packed, "attn_fwd: packed-bias flag without a bias");
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.out = out;
     p.bias_alt = bias_alt; p.bias_sel = (const int*)bias_sel;
@@ -475,7 +534,7 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;
-    p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = accumulate;
+    p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = accumulate; p.bias_packed = bias_packed;
     p.k2 = nullptr; p.v2 = nullptr; p.Nk2 = 0; p.k2_bs = p.k2_rs = p.v2_bs = p.v2_rs = 0; p.out_scale2 = 0.f;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, stream);
@@ -508,7 +567,7 @@ extern "C" int im360_attn_fwd2(const void* q, const void* k, const void* v, cons
     p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = 0;
-    p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = 0;
+    p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = 0; p.bias_packed = 0;
     p.k2 = k2; p.v2 = v2; p.Nk2 = (int)Nk2; p.k2_bs = k2_bs; p.k2_rs = k2_rs; p.v2_bs = v2_bs; p.v2_rs = v2_rs; p.out_scale2 = out_scale2;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, stream);

@@ -182,6 +182,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
     }
 }
 
+// bias [n] (16-bit) -> fp16 [n] = bias * log2(e): the form attn_fwd's packed-bias kernels feed to the matrix pipe
+template <typename T>
+__global__ void attn_pack_bias_kernel(const T* __restrict__ b, _Float16* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = (_Float16)(to_f32(b[i]) * 1.4426950408889634f);
+}
+
 }  // namespace im360
 
 // y[r] = LN(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod]; pre/post optional
@@ -246,6 +253,22 @@ extern "C" int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t 
                            (_Float16*)y, (long)rows, (long)cols, (long)x_rs, (long)y_rs, scale);
     else {
         im360_set_error("softmax_rows: dtype %d unsupported", dtype);
+        return IM360_ERR_UNSUPPORTED;
+    }
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// out_f16[i] = fp16(bias[i] * log2(e)), i < n: once per bias matrix (they are cached per resolution)
+extern "C" int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(bias && out_f16 && n > 0, "attn_pack_bias: null pointer / empty");
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == 0) hipLaunchKernelGGL((attn_pack_bias_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)bias, (_Float16*)out_f16, (long)n);
+    else if (dtype == 1) hipLaunchKernelGGL((attn_pack_bias_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)bias, (_Float16*)out_f16, (long)n);
+    else {
+        im360_set_error("attn_pack_bias: dtype %d unsupported", dtype);
         return IM360_ERR_UNSUPPORTED;
     }
     IM360_CHECK_LAUNCH();

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
+    "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_circular_pad_hw": (_INT, [_PTR] * 2 + [_I64] * 8 + [_PTR]),
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR, _PTR]),
@@ -100,11 +101,26 @@ def _p(t):
 
 
 # ------------------------------------------------------------------------------------------ attention
+def pack_attn_bias(bias):
+    """bias (16-bit, any shape) -> fp16 ``bias * log2(e)``: the form ``attention(..., bias_packed=True)`` feeds to the
+    matrix pipe (head dim 32, Nk % 8 == 0).  Once per cached mask."""
+    _dev(bias)
+    b = bias.contiguous()
+    out = torch.empty(b.shape, dtype=torch.float16, device=b.device)
+    _check(lib().im360_attn_pack_bias(_p(b), _p(out), b.numel(), _dt(b), _stream()), "im360_attn_pack_bias")
+    return out
+
+
+def can_pack_attn_bias(d, nk):
+    return d == 32 and nk % 8 == 0
+
+
 def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
-              bias_alt=None, bias_sel=None):
+              bias_alt=None, bias_sel=None, bias_packed=False):
     """q [B, Nq, heads*d], k/v [B / kv_group, Nk, heads*d] (last dim contiguous, any row/batch stride),
     bias [Nq, Nk] shared by every (batch, head); with ``bias_sel`` (device int32 scalar) the kernel picks
-    ``bias_alt`` when it is non-zero.  Returns out [B, Nq, heads*d]."""
+    ``bias_alt`` when it is non-zero.  ``bias_packed``: bias / bias_alt come from ``pack_attn_bias``.
+    Returns out [B, Nq, heads*d]."""
     _dev(q, k, v, bias, out)
     B, Nq, C = q.shape
     Nk = k.shape[1]
@@ -116,13 +132,14 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
         out = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
     assert out.stride(2) == 1
     if bias is not None:
-        assert bias.shape == (Nq, Nk) and bias.stride(1) == 1 and bias.dtype == q.dtype
+        assert bias.shape == (Nq, Nk) and bias.stride(1) == 1 and bias.dtype == (torch.float16 if bias_packed else q.dtype)
+        assert bias_alt is None or bias_alt.dtype == bias.dtype
     if scale is None:
         scale = d ** -0.5
     rc = lib().im360_attn_fwd(_p(q), _p(k), _p(v), _p(bias), _p(out), B, heads, Nq, Nk, d,
                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                               out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0, kv_group,
-                              float(scale), float(out_scale), int(accumulate), _dt(q), _stream(), _p(bias_alt), _p(bias_sel))
+                              float(scale), float(out_scale), int(accumulate), _dt(q) + (256 if bias_packed else 0), _stream(), _p(bias_alt), _p(bias_sel))
     _check(rc, "im360_attn_fwd")
     _count("attn", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
            + (0 if bias is None else bias.element_size() * Nq * Nk))

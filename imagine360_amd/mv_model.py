@@ -75,7 +75,12 @@ class WarpAttn(nn.Module):
                 pc, ec = G.spherical_coords(ph, pw, eh, ew, cameras)
                 pers_pe = self.pe(pc.to(device)).reshape(-1, self.dim)          # (m h w) c
                 equi_pe = self.pe(ec.to(device)).reshape(-1, self.dim)          # (h w) c
-                self._geom[key] = (b_e2p.to(dtype), b_p2e.to(dtype), pers_pe.to(dtype), equi_pe.to(dtype))
+                b_e2p, b_p2e = b_e2p.to(dtype), b_p2e.to(dtype)
+                # head dim 32: the masks go to the kernel as fp16 * log2(e) and are added by the matrix pipe
+                packed = all(kernels.can_pack_attn_bias(32, b.shape[1]) for b in (b_e2p, b_p2e))
+                if packed:
+                    b_e2p, b_p2e = kernels.pack_attn_bias(b_e2p), kernels.pack_attn_bias(b_p2e)
+                self._geom[key] = (b_e2p, b_p2e, pers_pe.to(dtype), equi_pe.to(dtype), packed)
         return self._geom[key]
 
     def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None):
@@ -89,12 +94,12 @@ class WarpAttn(nn.Module):
         m = nf // ne_img
         alt_e2p = alt_p2e = None
         if sel is not None:
-            b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, False, pers.device, pers.dtype)
-            alt_e2p, alt_p2e, _, _ = self.geometry(ph, pw, eh, ew, cameras, True, pers.device, pers.dtype)
+            b_e2p, b_p2e, pers_pe, equi_pe, packed = self.geometry(ph, pw, eh, ew, cameras, False, pers.device, pers.dtype)
+            alt_e2p, alt_p2e, _, _, _ = self.geometry(ph, pw, eh, ew, cameras, True, pers.device, pers.dtype)
         else:
             if opposite is None:
                 opposite = random.random() < 0.4                 # the reference's coin, one draw per call
-            b_e2p, b_p2e, pers_pe, equi_pe = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
+            b_e2p, b_p2e, pers_pe, equi_pe, packed = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
         eq = equi.reshape(b * frames, eh * ew, c)
         # (b m) f (h w) c -> (b f) (m h w) c
         pr = pers.reshape(b, m, frames, ph * pw, c).permute(0, 2, 1, 3, 4).reshape(b * frames, m * ph * pw, c)
@@ -102,8 +107,8 @@ class WarpAttn(nn.Module):
         pr_n = layer_norm(t.norm1, pr, pre=pers_pe)
         qkv_e, qkv_p = t.attn1.qkv(eq_n), t.attn1.qkv(pr_n)
         h = t.attn1.heads
-        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel)
-        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel)
+        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel, bias_packed=packed)
+        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed)
         # residual adds ride in the GEMM epilogues where the token count takes the MFMA kernel (same rounding sequence as
         # Linear -> + residual; hipBLASLt + add otherwise)
         eq = t.attn1.out_proj(a_e, residual=eq)

@@ -25,6 +25,8 @@ const char* im360_last_error(void);
  * bias_alt / bias_sel (optional): a second [Nq, Nk] bias and a device int32; the kernel uses bias_alt when
  *   *bias_sel != 0 (WarpAttn's normal / antipodal mask choice made on the device, so a step can be graph-replayed).
  * kv_group: K/V batch index = query batch index / kv_group (one context per video, F frames of queries).
+ * dtype: 0 bf16, 1 fp16; + 256 (D = 32 only, Nk % 8 == 0): bias and bias_alt are fp16 matrices already multiplied by
+ *   log2(e) (im360_attn_pack_bias) and are added to the scores by the matrix pipe instead of the vector ALU.
  * Replaces: xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
  *   diffusers/models/attention_processor.py:1264, 1351, 641 (spatial self / cross attention),
  *   animatediff/models/attention.py:113-148 (text + IP cross attention),
@@ -35,6 +37,10 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
                    int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
                    const void* bias_alt, const void* bias_sel);
+
+/* out_f16[i] = fp16(bias[i] * log2(e)) for the n elements of a bias matrix of dtype 0 / 1: the packed form accepted by
+ * im360_attn_fwd with dtype + 256.  Done once per (resolution, camera rig) -- WarpAttn's masks are cached. */
+int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, void* stream);
 
 /* Two key / value sets for the same queries in one launch (head dim 64, no bias):
  *   out = out_scale * softmax(q k^T scale) v + out_scale2 * softmax(q k2^T scale) v2

@@ -12,10 +12,16 @@ import torch
 import torch.nn.functional as F
 
 
+def pack_attn_bias(bias):
+    return (bias.float() * 1.4426950408889634).half()
+
+
 def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
-              bias_alt=None, bias_sel=None):
+              bias_alt=None, bias_sel=None, bias_packed=False):
     if bias_sel is not None and int(bias_sel) != 0:
         bias = bias_alt
+    if bias is not None and bias_packed:
+        bias = bias.float() / 1.4426950408889634
     B, Nq, C = q.shape
     d = C // heads
     if kv_group > 1:
@@ -165,7 +171,7 @@ def linear_geglu(x, w, b, inner):
 
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
-          "conv2d", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2"]
+          "conv2d", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2", "pack_attn_bias"]
 
 
 @contextlib.contextmanager

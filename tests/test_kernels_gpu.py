@@ -126,6 +126,37 @@ def test_attention_two_query_blocks_per_wave_variant(dt):
         K.tuning_set("attn_qb", 0)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 600, 328), (1, 2, 40, 80), (3, 3, 100, 1280), (2, 10, 2048, 512)])
+def test_attention_packed_bias_through_the_matrix_pipe(dt, B, H, Nq, Nk):
+    """WarpAttn's additive mask as fp16 * log2(e) fragments added by two f16 MFMAs per score block (dtype + 256,
+    kernels.pack_attn_bias) instead of unpack + FMA on the vector ALU: against the fp32 oracle and the unpacked-bias kernel,
+    ragged key counts (Nk % 8 == 0), 1 / 2 / 4 waves, one and two query blocks per wave, and the device-side mask switch."""
+    g = torch.Generator().manual_seed(86)
+    D = 32
+    q, k, v = (q16(torch.randn(B, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
+    bias = q16(torch.where(torch.rand(Nq, Nk, generator=g) < 0.3, 1.0, -1.0) + 0.25 * torch.randn(Nq, Nk, generator=g), dt)
+    alt = q16(-bias, dt)
+    dq, dk, dv, db, da = (t.to(dt).cuda() for t in (q, k, v, bias, alt))
+    pb, pa = K.pack_attn_bias(db), K.pack_attn_bias(da)
+    assert pb.dtype == torch.float16 and torch.allclose(pb.float().cpu(), bias * 1.4426950408889634, rtol=1e-3, atol=1e-3)
+    ref, ref_alt = OU.sdpa(q, k, v, H, bias=bias), OU.sdpa(q, k, v, H, bias=alt)
+    try:
+        for qb in (1, 2):
+            K.tuning_set("attn_qb", qb)
+            out = K.attention(dq, dk, dv, H, bias=pb, bias_packed=True)
+            assert rel(out, ref) < TOL[dt], qb
+            assert rel(out, K.attention(dq, dk, dv, H, bias=db).float().cpu()) < TOL[dt]
+            for flag, want in ((0, ref), (1, ref_alt)):
+                sel = torch.tensor([flag], dtype=torch.int32, device="cuda")
+                assert rel(K.attention(dq, dk, dv, H, bias=pb, bias_alt=pa, bias_sel=sel, bias_packed=True), want) < TOL[dt]
+    finally:
+        K.tuning_set("attn_qb", 0)
+    with pytest.raises(RuntimeError, match="head dim 32"):
+        x = torch.zeros(1, 64, 128, dtype=dt, device="cuda")
+        K.attention(x, x, x, 2, bias=torch.zeros(64, 64, dtype=torch.float16, device="cuda"), bias_packed=True)
+
+
 def test_attention_softmax_rescale_branch():
     """Force the running max to jump in a late KV tile (spiked key) -- the online-softmax rescale path."""
     dt = torch.bfloat16
