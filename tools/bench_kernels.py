@@ -43,8 +43,8 @@ def bench_attn(iters):
               ("warp L2 e2p", 32, 20, 512, 1280, 32, True)]
     for name, B, H, Nq, Nk, D, bias in shapes:
         q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
-        bb = (torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT) if bias else None
-        t = timeit(lambda: K.attention(q, k, v, H, bias=bb), iters)
+        bb = K.pack_attn_bias((torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT)) if bias else None      # the form WarpAttn caches
+        t = timeit(lambda: K.attention(q, k, v, H, bias=bb, bias_packed=bias), iters)
         fl = 4.0 * B * H * Nq * Nk * D
         print(f"attn  {name:20s} B={B:4d} H={H:2d} Nq={Nq:5d} Nk={Nk:5d} d={D}: {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TF/s "
               f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
