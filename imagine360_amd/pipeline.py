@@ -231,7 +231,7 @@ class AnimationPipeline:
                           fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers, reference_images_clip_feat_pano=feat_pano,
                           reference_images_clip_feat_pers=feat_pers, relative_position_tensor=rel, pitchs_tensor=pitch)
             graphed = GraphedDenoiseStep(self.mv_base_model, self.scheduler, inputs, cameras, pano_latent, pers_latent,
-                                         guidance_scale_text, use_fps=use_fps_condition)
+                                         guidance_scale_text, use_fps=use_fps_condition, warmup=1)       # one eager step fills every cache
         for i, t in enumerate(self.progress_bar(steps_host)):
             if graphed is not None:
                 pano_latent, pers_latent = graphed.step(t)
