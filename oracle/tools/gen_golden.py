@@ -337,7 +337,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys"]
+    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad"]      # "pipeline25": ~25 min, on request
     os.makedirs(GOLD, exist_ok=True)
     for w in which:
         globals()["gen_" + w]()
