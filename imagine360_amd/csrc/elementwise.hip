@@ -99,6 +99,99 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Packed rows for C = 320 / 640 (NCH = 40 / 80 sixteen-byte chunks per row): a wave takes 320 consecutive chunks = 8 / 4
+// whole rows, five per lane, as ONE contiguous 5 KB stream -- every lane loads (the row-per-wave form uses 40 of 64 lanes
+// at C = 320) and five loads per lane are in flight.  A chunk's row is (k * 64 + lane) / NCH, so the row statistics go
+// through a 320-float LDS scratch per wave: chunk sums in, NCH / 5 lanes per row add five each and finish with xor
+// shuffles, row values out.  Same two-pass (mean, then centred squares) arithmetic as the kernel above.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_packed_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta, const T* __restrict__ pre,
+                                                                const T* __restrict__ post, T* __restrict__ y, long rows,
+                                                                long pre_period, long post_div, long post_mod, float eps) {
+    constexpr int C = NCH * 8, R = 320 / NCH, G = NCH / 5;          // rows per wave, lanes per row in the reduction
+    static_assert(320 % NCH == 0 && NCH % 5 == 0 && 64 % G == 0 && R * G == 64, "packing");
+    __shared__ float scratch[4][320 + 2 * R];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* sc = scratch[wv];
+    const long row0 = ((long)blockIdx.x * 4 + wv) * R;
+    if (row0 >= rows) return;
+    const int nrow = rows - row0 < R ? (int)(rows - row0) : R;
+    int rk[5], ck[5];                                               // row (inside the wave's group) and chunk column of slot k
+    float v[5][8];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = k * 64 + lane;
+        rk[k] = i / NCH;
+        ck[k] = i % NCH;
+        const long row = row0 + (rk[k] < nrow ? rk[k] : nrow - 1);            // tail rows re-read the last valid row, never stored
+        unpack8<T>(*(const uint4*)(x + row * C + ck[k] * 8), v[k]);
+        if (pre) {
+            float a[8];
+            unpack8<T>(*(const uint4*)(pre + (row % pre_period) * C + ck[k] * 8), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] += a[e];
+        }
+    }
+    // row reduction of one float per chunk: returns, for each of the lane's five slots, the total of that slot's row
+    auto row_totals = [&](const float (&part)[5], float (&tot)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sc[k * 64 + lane] = part[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int r = lane / G, q = lane % G;
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) t += sc[r * NCH + q * 5 + j];
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o);
+        if (q == 0) sc[320 + r] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) tot[k] = sc[320 + rk[k]];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                              // scratch is reused by the next reduction
+    };
+    float part[5], mean[5], rstd[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        part[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[k] += v[k][e];
+    }
+    row_totals(part, mean);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        mean[k] *= 1.0f / (float)C;
+        part[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = v[k][e] - mean[k];
+            part[k] += d * d;
+        }
+    }
+    row_totals(part, rstd);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        rstd[k] = rsqrtf(rstd[k] * (1.0f / (float)C) + eps);
+        if (rk[k] >= nrow) continue;
+        const long row = row0 + rk[k];
+        float g[8], b[8], o[8];
+        unpack8<T>(*(const uint4*)(gamma + ck[k] * 8), g);
+        unpack8<T>(*(const uint4*)(beta + ck[k] * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[k][e] - mean[k]) * rstd[k] * g[e] + b[e];
+        if (post) {
+            float a[8];
+            unpack8<T>(*(const uint4*)(post + ((row / post_div) % post_mod) * C + ck[k] * 8), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
+        *(uint4*)(y + row * C + ck[k] * 8) = pack8<T>(o);
+    }
+}
+
 // h [rows, 2*I] = (a | gate) -> out [rows, I] = a * gelu(gate), exact (erf) GELU
 template <typename T>
 __global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8) {
@@ -124,11 +217,18 @@ static int launch_ln(const void* x, const void* gamma, const void* beta, const v
     hipLaunchKernelGGL((layernorm_kernel<T, MC, R>), dim3((unsigned)((rows + 4 * R - 1) / (4 * R))), dim3(256), 0, \
                        s, (const T*)x, (const T*)gamma, (const T*)beta, (const T*)pre, (const T*)post, (T*)y,     \
                        rows, C, pre_period, post_div, post_mod, eps)
-    if (nch <= 64) IM360_LN(1, 4);
+#define IM360_LNP(NCH)                                                                                             \
+    hipLaunchKernelGGL((layernorm_packed_kernel<T, NCH>), dim3((unsigned)((rows + 4 * (320 / NCH) - 1) / (4 * (320 / NCH)))), \
+                       dim3(256), 0, s, (const T*)x, (const T*)gamma, (const T*)beta, (const T*)pre, (const T*)post, \
+                       (T*)y, rows, pre_period, post_div, post_mod, eps)
+    // measured (tools/bench_kernels.py ln): C = 320 packed 0.173 vs 0.232 ms at 655 360 rows; C = 640 loses (0.088 vs 0.080)
+    if (nch == 40 && knob(KNOB_TATTN_SCALAR) != 2) IM360_LNP(40);           // (knob tattn_scalar = 2: A/B against the row-per-wave kernel)
+    else if (nch <= 64) IM360_LN(1, 4);
     else if (nch <= 128) IM360_LN(2, 2);
     else if (nch <= 192) IM360_LN(3, 1);
     else IM360_LN(4, 1);
 #undef IM360_LN
+#undef IM360_LNP
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -510,7 +510,7 @@ def test_bad_arguments_fail_loudly():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 64), (513, 1280), (40, 1024), (9, 2048)])
+@pytest.mark.parametrize("rows,C", [(1000, 320), (1003, 320), (5, 320), (999, 640), (2, 640), (77, 64), (513, 1280), (40, 1024), (9, 2048)])
 def test_layer_norm_plain_pre_post(dt, rows, C):
     x = q16(rnd(rows, C, seed=40) * 1.3 + 0.2, dt)
     g, b = q16(1 + 0.1 * rnd(C, seed=41), dt), q16(0.1 * rnd(C, seed=42), dt)
