@@ -102,12 +102,28 @@ def _synthetic_module(name):
     return mod
 
 
-def install(force=False):
+def _preprocess_aliases():
+    """Opt-in (``install(preprocess=True)``): the host preprocessing geometry of SURVEY row N3 on the GPU.  Not part of the
+    default overlay because the bicubic arithmetic of cv2.remap is restated without OpenCV to check it against."""
+    from . import preprocess
+    return {
+        "src.utils.pano_utils.Equirec2Perspec": dict(Equirectangular=preprocess.Equirectangular),
+        "src.utils.pano_utils.Perspec2Equirec": dict(Perspective=preprocess.Perspective),
+        "animatediff.utils.video_mask": dict(get_anchor_target=preprocess.get_anchor_target),
+        "src.modules.utils": dict(flush=_flush, get_maxrec_cord=preprocess.get_maxrec_cord),
+    }
+
+
+def install(force=False, preprocess=False):
     """Overlay the hot-path names (see the module docstring).  Returns {module name: "overlay" | "synthetic"}.
-    ``force`` is accepted for backward compatibility; already-imported reference modules are patched in place."""
+    ``force`` is accepted for backward compatibility; already-imported reference modules are patched in place.
+    ``preprocess``: also route the script's E2P / P2E warps, get_anchor_target and get_maxrec_cord to the MI355X versions."""
     done = {}
     originals = {}
-    for name, attrs in _ALIASES.items():
+    aliases = dict(_ALIASES)
+    if preprocess:
+        aliases.update(_preprocess_aliases())
+    for name, attrs in aliases.items():
         real = sys.modules.get(name)
         if real is None or getattr(real, "__im360_alias__", False):
             real = _import_real(name) if real is None else real

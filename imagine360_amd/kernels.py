@@ -26,6 +26,8 @@ _SIGNATURES = {
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
+    "im360_remap_cubic_wrap_u8": (_INT, [_PTR] * 5 + [_I64] * 7 + [_PTR]),
+    "im360_max_rect": (_INT, [_PTR, _I64, _I64, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_circular_pad_hw": (_INT, [_PTR] * 2 + [_I64] * 8 + [_PTR]),
     "im360_cfg_ddim_update": (_INT, [_PTR] * 4 + [_I64] + [_F32] * 3 + [_INT, _PTR, _PTR]),
@@ -387,6 +389,31 @@ def circular_pad_hw(x, left, right, top=0, bottom=0):
     rc = lib().im360_circular_pad_hw(_p(x), _p(y), n, H, W, left, right, top, bottom, x.element_size(), _stream())
     _check(rc, "im360_circular_pad_hw")
     return y
+
+
+def remap_cubic_wrap(img, map_x, map_y, wtab):
+    """``cv2.remap(img[n], map_x[m], map_y[m], INTER_CUBIC, BORDER_WRAP)`` for every (n, m): img uint8 [N, H, W, C] on the
+    device, maps float32 [M, h, w], wtab int16 [1024, 16] -> uint8 [N, M, h, w, C]."""
+    _dev(img, map_x, map_y, wtab)
+    assert img.dtype == torch.uint8 and img.dim() == 4 and img.is_contiguous()
+    assert map_x.dtype == torch.float32 and map_x.shape == map_y.shape and map_x.dim() == 3 and map_x.is_contiguous() and map_y.is_contiguous()
+    assert wtab.dtype == torch.int16 and wtab.shape == (1024, 16) and wtab.is_contiguous()
+    N, H, W, C = img.shape
+    M, h, w = map_x.shape
+    out = torch.empty((N, M, h, w, C), dtype=torch.uint8, device=img.device)
+    rc = lib().im360_remap_cubic_wrap_u8(_p(img), _p(map_x), _p(map_y), _p(wtab), _p(out), N, M, H, W, C, h, w, _stream())
+    _check(rc, "im360_remap_cubic_wrap_u8")
+    return out
+
+
+def max_rect(mask):
+    """Largest all-ones rectangle of a host mask [H, W] -> (top, left, width, height) (reference scan order / ties)."""
+    import numpy as np
+    m = np.ascontiguousarray(np.asarray(mask) == 1, dtype=np.uint8)
+    rect = (ctypes.c_int64 * 4)()
+    rc = lib().im360_max_rect(m.ctypes.data, m.shape[0], m.shape[1], ctypes.addressof(rect))
+    _check(rc, "im360_max_rect")
+    return tuple(int(v) for v in rect)
 
 
 def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):

@@ -147,6 +147,21 @@ int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_pac
 int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
                        float scale, int dtype, void* stream);
 
+/* out[n][m] = cv2.remap(img[n], map_x[m], map_y[m], INTER_CUBIC, borderMode=BORDER_WRAP): uint8 images [N, H, W, C]
+ * (C = 1, 3, 4) on the device, float32 maps [M, h, w] in source pixel units, out uint8 [N, M, h, w, C]; wtab = the
+ * 1024 x 16 int16 bicubic weight table (imagine360_amd.preprocess.cubic_weight_table).  One launch warps every frame through
+ * every camera's map.  OpenCV's fixed-point arithmetic restated (parity unpinned: OpenCV is not available to check it).
+ * Replaces: the cv2.remap calls of Equirec2Perspec.GetPerspective / Perspec2Equirec.GetEquirec,
+ *   src/utils/pano_utils/Equirec2Perspec.py:61, Perspec2Equirec.py:65, looped per frame and view by process_equi /
+ *   pers2pano_vid / get_anchor_target (inference_dual_p2e.py:113-144, 291-304; animatediff/utils/video_mask.py:158-217). */
+int im360_remap_cubic_wrap_u8(const void* img, const void* map_x, const void* map_y, const void* wtab, void* out,
+                              int64_t N, int64_t M, int64_t H, int64_t W, int64_t C, int64_t h, int64_t w, void* stream);
+
+/* Largest all-ones rectangle of a HOST uint8 mask [H, W]: rect[4] = (top, left, width, height), scan order and
+ * tie-breaking of the reference's Python loops.  Host code (no GPU involved).
+ * Replaces: get_maxrec_cord, src/modules/utils.py:39-73. */
+int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
+
 /* A/B switches of the host-side launchers (knob ids: 0 attention query blocks per wave, 1 conv tile policy: 0 never the
  * 256x320 tile, 2 / 3 two-workgroup 128x320 / 128x256 tiles, 2 force 32-channel K steps, 3 scalar temporal attention,
  * 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring

@@ -317,6 +317,79 @@ def gen_srpad():
     save("sr_pad.npz", **out)
 
 
+def gen_preproc():
+    """Host preprocessing geometry.  The REAL Equirec2Perspec / Perspec2Equirec modules are imported
+    through ref_shims (cv2.Rodrigues restated) with cv2.remap replaced by a recorder, so the fixture holds the sampling
+    maps and masks the reference hands to cv2.remap; the real get_maxrec_cord (pure Python) gives the rectangle fixtures.
+    cv2.remap's own arithmetic is NOT in the fixture (OpenCV is absent): parity unpinned for it, see the oracle header."""
+    import hashlib
+    print("[preproc]")
+    ref_shims.ref_modules()
+    import cv2
+    from im360_oracle import preprocess as OPP
+    rec = []
+
+    def recorder(img, mx, my, interp, borderMode=None):
+        rec.append((np.array(mx), np.array(my)))
+        return np.zeros(mx.shape + (img.shape[2],), img.dtype)
+    cv2.remap = recorder
+    import src.utils.pano_utils.Equirec2Perspec as E2P
+    import src.utils.pano_utils.Perspec2Equirec as P2E
+    from src.modules.utils import get_maxrec_cord as ref_maxrec
+    out = {}
+    cams = [(0.0, 0.0), (36.0, 52.6), (-108.0, -10.8), (180.0, 90.0), (72.0, -52.6)]
+    pano = np.zeros((64, 128, 3), np.uint8)
+    for n, (th, ph) in enumerate(cams):
+        rec.clear()
+        E2P.Equirectangular(pano).GetPerspective(90, th, ph, 32, 32)
+        lon, lat = rec[0]
+        olon, olat = OPP.e2p_maps(90, th, ph, 32, 32, 64, 128)
+        assert np.array_equal(lon, olon) and np.array_equal(lat, olat), ("e2p", n)
+        out[f"e2p_lon_{n}"], out[f"e2p_lat_{n}"] = lon, lat
+    # the production geometry (20 icosahedron views of 256 x 256 out of 512 x 1024) as a digest
+    from src.utils.pano import icosahedron_sample_camera
+    thetas, phis = icosahedron_sample_camera()
+    thetas, phis = np.rad2deg(thetas), np.rad2deg(phis)
+    h = hashlib.sha256()
+    big = np.zeros((512, 1024, 3), np.uint8)
+    for th, ph in zip(thetas, phis):
+        rec.clear()
+        E2P.Equirectangular(big).GetPerspective(90, th, ph, 256, 256)
+        olon, olat = OPP.e2p_maps(90, th, ph, 256, 256, 512, 1024)
+        assert np.array_equal(rec[0][0], olon) and np.array_equal(rec[0][1], olat)
+        h.update(rec[0][0].tobytes())
+        h.update(rec[0][1].tobytes())
+    out["e2p_cfg2_thetas"], out["e2p_cfg2_phis"] = np.asarray(thetas, np.float64), np.asarray(phis, np.float64)
+    out["e2p_cfg2_sha256"] = np.frombuffer(h.digest(), np.uint8)
+    pers = np.zeros((24, 40, 3), np.uint8)
+    for n, (th, ph) in enumerate([(0.0, 0.0), (0.0, 17.5), (30.0, -40.0)]):
+        rec.clear()
+        _, mask = P2E.Perspective(pers, 90, th, ph).GetEquirec(48, 96)
+        lon, lat = rec[0]
+        olon, olat, omask = OPP.p2e_maps(90, th, ph, 24, 40, 48, 96)
+        assert np.array_equal(lon, olon) and np.array_equal(lat, olat) and np.array_equal(mask[..., 0], omask), ("p2e", n)
+        out[f"p2e_lon_{n}"], out[f"p2e_lat_{n}"], out[f"p2e_mask_{n}"] = lon, lat, mask[..., 0].astype(np.uint8)
+    g = np.random.default_rng(5)
+    rects = []
+    for n in range(6):
+        m = (g.random((24 + 4 * n, 37 + 3 * n)) < 0.8).astype(np.int64)
+        if n == 4:
+            m[:] = 1
+        if n == 5:
+            m[:] = 0
+        r = ref_maxrec(m)
+        assert tuple(int(v) for v in r) == OPP.get_maxrec_cord(m), n
+        out[f"rect_mask_{n}"] = m.astype(np.uint8)
+        rects.append([int(v) for v in r])
+    _, _, omask = OPP.p2e_maps(90, 0.0, 12.0, 256, 256, 256, 512)                  # the real use: largest rectangle of a P2E footprint
+    r = ref_maxrec(omask)
+    assert tuple(int(v) for v in r) == OPP.get_maxrec_cord(omask)
+    out["rect_p2e_phi12"] = np.asarray([int(v) for v in r])
+    out["rects"] = np.asarray(rects)
+    print("  oracle == reference: maps, masks, rectangles (bit-exact)")
+    save("preproc.npz", **out)
+
+
 def gen_keys():
     """State-dict keys/shapes of the full-width reference models (checkpoint compatibility)."""
     print("[keys]")
@@ -337,7 +410,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad"]      # "pipeline25": ~25 min, on request
+    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad", "preproc"]      # "pipeline25": ~25 min, on request
     os.makedirs(GOLD, exist_ok=True)
     for w in which:
         globals()["gen_" + w]()

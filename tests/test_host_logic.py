@@ -336,3 +336,46 @@ def test_sr_patch_module_mirrors_the_reference_helpers():
         sr_patch.padding_pano(g["lat"][0, 0, 0], latent=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sr_patch.padding_pano(g["lat"], latent=True)                 # the product path needs the HIP extension
+
+
+def test_preprocess_maps_table_and_rectangle_against_reference():
+    """imagine360_amd.preprocess, the parts that run on the host: sampling maps and masks == the real
+    reference's (fixture preproc.npz, incl. the digest of the 20 production maps), the weight table == the oracle's
+    independent construction, im360_max_rect (C, host) == the real get_maxrec_cord incl. all-ones / all-zeros masks and a
+    real P2E footprint."""
+    import hashlib
+    import numpy as np
+    import os
+    from helpers import GOLDEN
+    from im360_oracle import preprocess as OPP
+    from imagine360_amd import preprocess as PP
+    g = np.load(os.path.join(GOLDEN, "preproc.npz"))
+    for n, (th, ph) in enumerate([(0.0, 0.0), (36.0, 52.6), (-108.0, -10.8), (180.0, 90.0), (72.0, -52.6)]):
+        lon, lat = PP.e2p_maps(90.0, th, ph, 32, 32, 64, 128)
+        assert np.array_equal(lon, g[f"e2p_lon_{n}"]) and np.array_equal(lat, g[f"e2p_lat_{n}"])
+    h = hashlib.sha256()
+    for th, ph in zip(g["e2p_cfg2_thetas"], g["e2p_cfg2_phis"]):
+        lon, lat = PP.e2p_maps(90.0, float(th), float(ph), 256, 256, 512, 1024)
+        h.update(lon.tobytes())
+        h.update(lat.tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), np.uint8), g["e2p_cfg2_sha256"])
+    for n, (th, ph) in enumerate([(0.0, 0.0), (0.0, 17.5), (30.0, -40.0)]):
+        lon, lat, mask = PP.p2e_maps(90.0, th, ph, 24, 40, 48, 96)
+        assert np.array_equal(lon, g[f"p2e_lon_{n}"]) and np.array_equal(lat, g[f"p2e_lat_{n}"]) and np.array_equal(mask, g[f"p2e_mask_{n}"])
+    assert np.array_equal(PP.cubic_weight_table(), OPP.cubic_weight_table())
+    for n in range(6):
+        assert PP.get_maxrec_cord(g[f"rect_mask_{n}"]) == tuple(int(v) for v in g["rects"][n])
+    _, _, m = PP.p2e_maps(90.0, 0.0, 12.0, 256, 256, 256, 512)
+    assert PP.get_maxrec_cord(torch.from_numpy(m)) == tuple(int(v) for v in g["rect_p2e_phi12"])
+
+
+def test_dropin_preprocess_aliases_are_opt_in():
+    """install(preprocess=True) adds the N3 names (E2P / P2E classes, get_anchor_target, get_maxrec_cord); the default
+    overlay leaves the script's preprocessing on the checkout (its cv2 arithmetic cannot be checked here)."""
+    from imagine360_amd import dropin, preprocess
+    extra = dropin._preprocess_aliases()
+    assert extra["src.utils.pano_utils.Equirec2Perspec"]["Equirectangular"] is preprocess.Equirectangular
+    assert extra["src.utils.pano_utils.Perspec2Equirec"]["Perspective"] is preprocess.Perspective
+    assert extra["animatediff.utils.video_mask"]["get_anchor_target"] is preprocess.get_anchor_target
+    assert extra["src.modules.utils"]["get_maxrec_cord"] is preprocess.get_maxrec_cord
+    assert not any(k.startswith("src.utils.pano_utils") or k == "animatediff.utils.video_mask" for k in dropin._ALIASES)

@@ -402,3 +402,52 @@ def test_ops_vs_reference_fixture(dt, tol):
     errs["conv_in_pano"] = rel(from_cl(un.conv_in_cl(l9, pano=True), f), g["conv_in_pano"])
     _record(f"ops_w5_{str(dt).split('.')[-1]}", **errs)
     assert max(errs.values()) < tol, errs
+
+
+def test_preprocessing_warps_vs_oracle():
+    """SURVEY row N3 on the GPU: im360_remap_cubic_wrap_u8 == the oracle's restatement of cv2.remap(INTER_CUBIC, BORDER_WRAP)
+    bit for bit -- random maps incl. coordinates outside the image, exact .5 / integer positions and 1 / 3 / 4 channels --
+    and the script-level helpers built on it (process_equi, pers2pano_frames, Equirectangular / Perspective, get_anchor_target)
+    == the same compositions of the oracle.  (The maps themselves are pinned on the real reference in the CPU tests; the
+    bicubic arithmetic is parity-unpinned, see the oracle header.)"""
+    import numpy as np
+    from im360_oracle import preprocess as OPP
+    from imagine360_amd import preprocess as PP
+    rng = np.random.default_rng(3)
+    for C in (1, 3, 4):
+        img = rng.integers(0, 256, (2, 37, 53, C), dtype=np.uint8)
+        mx = (rng.random((3, 20, 31)) * 80 - 15).astype(np.float32)
+        my = (rng.random((3, 20, 31)) * 60 - 12).astype(np.float32)
+        mx[0, 0, :8] = [0.0, 0.5, 1.5, 52.0, 52.984375, -0.015625, 53.0, -1.0]
+        my[0, 0, :8] = [0.0, 0.5, 2.5, 36.0, 36.5, -0.5, 37.0, -4.0]
+        got = PP.remap(torch.from_numpy(img).cuda(), torch.from_numpy(mx).cuda(), torch.from_numpy(my).cuda()).cpu().numpy()
+        for n in range(2):
+            for m in range(3):
+                assert np.array_equal(got[n, m], OPP.remap_cubic_wrap_u8(img[n], mx[m], my[m])), (C, n, m)
+    pano = torch.from_numpy(rng.random((2, 3, 64, 128)).astype(np.float32) * 2 - 1)
+    thetas, phis = np.array([0.0, 72.0, -108.0, 180.0]), np.array([0.0, 52.6, -10.8, 90.0])
+    out = PP.process_equi(pano, torch.from_numpy(thetas)[None], torch.from_numpy(phis)[None], pers_resolution=32)
+    ref = OPP.process_equi(pano.numpy(), thetas, phis, pers_resolution=32)
+    assert out.shape == (2, 4, 3, 32, 32) and np.array_equal(out.numpy(), ref)
+    valid = PP.process_equi(pano.abs(), thetas, phis, pers_resolution=32, back_norm=False)
+    assert np.array_equal(valid.numpy(), OPP.process_equi(pano.abs().numpy(), thetas, phis, pers_resolution=32, back_norm=False))
+    frames = rng.integers(0, 256, (3, 24, 40, 3), dtype=np.uint8)
+    pf, pm = PP.pers2pano_frames(frames, [0.0, 17.5, 0.0], pano_H=48, pano_W=96)
+    rf, rm = OPP.pers2pano_frames(frames, [0.0, 17.5, 0.0], pano_h=48, pano_w=96)
+    assert np.array_equal(pf, rf) and np.array_equal(pm, rm)
+    one = PP.Equirectangular(frames[0]).GetPerspective(90, 30.0, -20.0, 16, 16)
+    assert np.array_equal(one, OPP.get_perspective(frames[0], 90, 30.0, -20.0, 16, 16))
+    canvas, mask = PP.Perspective(frames[1], 90, 0, 10.0).GetEquirec(48, 96)
+    rc, rmask = OPP.get_equirec(frames[1], 90, 0, 10.0, 48, 96)
+    assert np.array_equal(canvas, rc) and np.array_equal(mask, rmask)
+    vid = torch.from_numpy(rng.random((2, 3, 64, 128)).astype(np.float32) * 2 - 1).cuda()
+    a, ap, tgt, masks, rel_pos, pitchs = PP.get_anchor_target(vid, [5.0, -12.0])
+    assert a.shape == (1, 2, 3, 256, 256) and ap.shape == (1, 2, 3, 32, 32) and masks.shape == (1, 2, 1, 64, 128)
+    assert rel_pos.shape == (1, 2, 6) and pitchs.shape == (1, 2) and torch.equal(tgt, vid[None])
+    for i, ph in enumerate([5.0, -12.0]):
+        fr = ((vid[i].permute(1, 2, 0).cpu().numpy() + 1) / 2 * 255).astype(np.uint8)
+        assert np.array_equal(((ap[0, i].permute(1, 2, 0).cpu().numpy() + 1) * 127.5).round().astype(np.uint8), OPP.get_perspective(fr, 90, 0, ph, 32, 32))
+        _, _, m = OPP.p2e_maps(90, 0, ph, 32, 32, 64, 128)
+        assert np.array_equal(masks[0, i, 0].cpu().numpy(), (1 - m).astype(np.float32))
+        top, left, rw, rh = OPP.get_maxrec_cord(m)
+        assert rel_pos[0, i].tolist() == [int(32 - (2 * top + rh) / 2), int(64 - (2 * left + rw) / 2), rh, rw, 64, 128]

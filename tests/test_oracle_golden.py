@@ -134,3 +134,35 @@ def test_sr_close_loop_pad_against_reference():
     assert OG.padding_pano(g["lat"], 0, latent=True) is g["lat"]
     with pytest.raises(NotImplementedError):
         OG.padding_pano(g["lat"][0, 0, 0], 16, latent=True)
+
+
+def test_preprocessing_geometry_against_reference():
+    """the oracle's E2P / P2E sampling maps and masks == the maps the REAL Equirec2Perspec / Perspec2Equirec
+    modules hand to cv2.remap, and its get_maxrec_cord == the real one (tests/golden/preproc.npz), bit-exact.  (cv2.remap's
+    own arithmetic is parity-unpinned: see the oracle header.)"""
+    import hashlib
+    import numpy as np
+    import os
+    from helpers import GOLDEN
+    from im360_oracle import preprocess as OPP
+    g = np.load(os.path.join(GOLDEN, "preproc.npz"))
+    for n, (th, ph) in enumerate([(0.0, 0.0), (36.0, 52.6), (-108.0, -10.8), (180.0, 90.0), (72.0, -52.6)]):
+        lon, lat = OPP.e2p_maps(90, th, ph, 32, 32, 64, 128)
+        assert np.array_equal(lon, g[f"e2p_lon_{n}"]) and np.array_equal(lat, g[f"e2p_lat_{n}"])
+    h = hashlib.sha256()
+    for th, ph in zip(g["e2p_cfg2_thetas"], g["e2p_cfg2_phis"]):
+        lon, lat = OPP.e2p_maps(90, th, ph, 256, 256, 512, 1024)
+        h.update(lon.tobytes())
+        h.update(lat.tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), np.uint8), g["e2p_cfg2_sha256"])
+    for n, (th, ph) in enumerate([(0.0, 0.0), (0.0, 17.5), (30.0, -40.0)]):
+        lon, lat, mask = OPP.p2e_maps(90, th, ph, 24, 40, 48, 96)
+        assert np.array_equal(lon, g[f"p2e_lon_{n}"]) and np.array_equal(lat, g[f"p2e_lat_{n}"]) and np.array_equal(mask, g[f"p2e_mask_{n}"])
+    for n in range(6):
+        assert OPP.get_maxrec_cord(g[f"rect_mask_{n}"]) == tuple(int(v) for v in g["rects"][n])
+    tab = OPP.cubic_weight_table()
+    assert tab.shape == (1024, 16) and (tab.astype(np.int64).sum(1) == 32768).all()
+    assert tab[0].reshape(4, 4)[1, 1] == 32767 and tab[0].reshape(4, 4)[2, 2] == 1      # integer position: saturated centre tap + the residue
+    img = np.random.default_rng(0).integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    yy, xx = np.meshgrid(np.arange(9, dtype=np.float32), np.arange(11, dtype=np.float32), indexing="ij")
+    assert np.array_equal(OPP.remap_cubic_wrap_u8(img, xx, yy), img)                    # identity map returns the image

@@ -167,6 +167,36 @@ def bench_srpad(iters):
         print(f"srpad {name:26s}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak) | torch F.pad circular {tt * 1e3:8.3f} ms")
 
 
+def bench_preproc(iters):
+    """Preprocessing warps: process_equi of a 16-frame 512 x 1024 panorama into 20 views of 256 x 256 --
+    one launch -- against the per-(frame, view) CPU restatement the oracle runs (and the reference's cv2 loop)."""
+    import time
+    import numpy as np
+    from imagine360_amd import preprocess as PP, synthetic as S
+    pano = torch.rand(16, 3, 512, 1024) * 2 - 1
+    th, ph = S.icosahedron_angles() if hasattr(S, "icosahedron_angles") else (np.linspace(-180, 180, 20), np.zeros(20))
+    th, ph = np.rad2deg(np.asarray(th, np.float64)), np.rad2deg(np.asarray(ph, np.float64))
+    PP.process_equi(pano, th, ph)                                  # builds + caches the 20 maps (host, float64)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        out = PP.process_equi(pano, th, ph)
+    torch.cuda.synchronize()
+    t_all = (time.time() - t0) / 3
+    frames = ((pano + 1) * 127.5).permute(0, 2, 3, 1).to(torch.uint8).cuda()
+    eq = PP.Equirectangular(frames)
+    t = timeit(lambda: eq.GetPerspectives(90, th, ph, 256, 256), iters)
+    px = 16 * 20 * 256 * 256
+    t0 = time.time()
+    for _ in range(3):
+        PP.process_equi(pano, th, ph, keep_on_device=True)
+    torch.cuda.synchronize()
+    t_dev = (time.time() - t0) / 3
+    print(f"preproc process_equi, result left on the device: {t_dev * 1e3:7.1f} ms per call")
+    print(f"preproc process_equi 16 x 512x1024 -> 16 x 20 x 256x256: warp kernel {t * 1e3:7.3f} ms ({px / t / 1e9:6.1f} Gpixel/s, "
+          f"{px * 3 / t / 1e9:6.0f} GB/s written); whole call incl. uploads / download {t_all * 1e3:7.1f} ms; output {tuple(out.shape)}")
+
+
 def bench_linear(iters):
     """torch F.linear (hipBLASLt) vs the implicit-GEMM kernel used as a 1x1 conv on the same shapes."""
     import torch.nn.functional as F
