@@ -222,7 +222,7 @@ static int launch_ln(const void* x, const void* gamma, const void* beta, const v
                        dim3(256), 0, s, (const T*)x, (const T*)gamma, (const T*)beta, (const T*)pre, (const T*)post, \
                        (T*)y, rows, pre_period, post_div, post_mod, eps)
     // measured (tools/bench_kernels.py ln): C = 320 packed 0.173 vs 0.232 ms at 655 360 rows; C = 640 loses (0.088 vs 0.080)
-    if (nch == 40 && knob(KNOB_TATTN_SCALAR) != 2) IM360_LNP(40);           // (knob tattn_scalar = 2: A/B against the row-per-wave kernel)
+    if (nch == 40 && knob(KNOB_LN_PACKED)) IM360_LNP(40);                   // (knob ln_packed = 0: A/B against the row-per-wave kernel)
     else if (nch <= 64) IM360_LN(1, 4);
     else if (nch <= 128) IM360_LN(2, 2);
     else if (nch <= 192) IM360_LN(3, 1);

@@ -167,7 +167,7 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring
  * (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring kernel for convolutions too; 5 reserved; 6 ablation bits of the
  * ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions; 8 taps-innermost K order of the 3x3 convolutions
- * (default 1)).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * (default 1); 9 packed-rows LayerNorm at 320 channels (default 1)).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
  * change the fp32 summation order, 6 breaks results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);
 

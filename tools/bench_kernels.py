@@ -129,9 +129,9 @@ def bench_ln(iters):
         x, g, b = rn(rows, C), rn(C), rn(C)
         t = timeit(lambda: K.layer_norm(x, g, b), iters)
         by = 2.0 * rows * C * 2
-        K.tuning_set("tattn_scalar", 2)          # A/B: the row-per-wave kernel at C = 320 / 640
+        K.tuning_set("ln_packed", 0)             # A/B: the row-per-wave kernel at C = 320
         t_old = timeit(lambda: K.layer_norm(x, g, b), iters)
-        K.tuning_set("tattn_scalar", 0)
+        K.tuning_set("ln_packed", 1)
         print(f"ln    {name:10s} rows={rows:7d} C={C:4d}: {t * 1e3:8.3f} ms  {by / t / 1e9:7.0f} GB/s ({by / t / 8e12 * 100:4.1f}% of HBM peak) | row-per-wave kernel {t_old * 1e3:8.3f} ms")
         h = rn(rows, 8 * C) if rows * C * 16 < 8e9 else None
         if h is not None:
