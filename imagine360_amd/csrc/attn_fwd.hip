@@ -87,9 +87,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const long nb = gridDim.x, qn = nb / 8, rn = nb % 8, xcd = lb % 8, idx = lb / 8;
         lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
     }
-    const int bh = (int)(lb / p.nqt);
+    // With a shared bias the [Nq, Nk] mask is the larger stream (256 query rows x Nk x 2 B per workgroup against
+    // Nk x d x 4 B of K / V: 4x at d = 32): query tile major, (batch, head) minor, so the workgroups resident on an XCD
+    // read the same mask rows out of its L2 and K / V come from the Infinity Cache instead of the other way round.
+    const long nbh = (long)p.B * p.H;
+    const int bh = HAS_BIAS ? (int)(lb % nbh) : (int)(lb / p.nqt);
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = (int)(lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
+    const int q0 = (int)(HAS_BIAS ? lb / nbh : lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
 
     const T* qb_ = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
     // the key / value set being processed (DUAL kernels switch to the second set after the first)
@@ -190,6 +194,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int l16 = lane & 15, half = (lane >> 4) & 1;
     const int vfrag = (4 * hi + (l16 >> 2)) * VP + 16 * half + 4 * (l16 & 3);
 
+    // BF with two query blocks per wave: the mask fragments of a 32-key half are requested ONE HALF AHEAD into the other of
+    // two register buffers (the buffer index is the half's parity, a compile-time constant): requested right in front of
+    // the two QK^T MFMAs that precede their use, their L2 latency stalled every half tile (SQ_WAIT_ANY 60 %).
+    constexpr bool BF_AHEAD = BF && QB > 1;
+    uint4 bfh[2][BF_AHEAD ? QB : 1][2];
+    auto fetch_half = [&](int key_base, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if constexpr (BF_AHEAD) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int key0 = min(key_base + 16 * c + 8 * hi, set_nk - 8);
+                    bfh[buf][qb][c] = *(const uint4*)(bias + (long)qrow[qb] * p.bias_rs + key0);
+                }
+        }
+    };
+
     // one 64-key tile against the wave's QB query blocks.  MASKED is only instantiated for a ragged last tile.
     auto tile_body = [&](int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -202,7 +224,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         uint4 bfm[BF ? QB : 1][2][2];          // BF: [query block][half][16-key chunk]: keys 16 c + 8 hi .. + 7 of the lane's query row
         auto load_bias = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            if constexpr (BF) {
+            if constexpr (BF_AHEAD) {
+                // this half's fragments are already in bfh[kb]; request the next half (of this tile or the next one)
+                fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 1 - kb>{});
+            } else if constexpr (BF) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -238,7 +263,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) s[qb][kb] = Elem<_Float16>::mfma32(idA[c], bfm[qb][QK_ALL ? kb : 0][c], s[qb][kb]);
+                    for (int c = 0; c < 2; ++c)
+                        s[qb][kb] = Elem<_Float16>::mfma32(idA[c], BF_AHEAD ? bfh[kb][BF_AHEAD ? qb : 0][c] : bfm[qb][QK_ALL ? kb : 0][c], s[qb][kb]);
             }
         };
         // online-softmax update of block qb over the halves [K0, K1), then O^T += V^T P^T for them
@@ -354,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     auto run_set = [&]() {
         load_tile(0);
+        fetch_half(0, std::integral_constant<int, 0>{});
         store_tile(0);
         if (ntiles > 1) load_tile(1);
         // a ragged last tile is peeled out of the loop: with both bodies inside it hipcc gave them different registers and
