@@ -4,4 +4,4 @@
 export PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=$PWD/gpurun_out/tunableop_results.csv
 export PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=30 PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS=5
 mkdir -p gpurun_out
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-tuned-gemms
+python bench.py --steps 3 --warmup 1 --cpu-baseline none --no-graph --no-tuned-gemms
