@@ -36,6 +36,7 @@ struct ConvParams {
     int tiles_n;        // ceil(Cout / 128)
     long nblocks;
     int halo_r, halo_seg, halo_pw, halo_p;      // halo kernel: output rows per tile, rows per image segment, patch width / pixels
+    int up2_py, up2_px; // UP2 kernels: output parity (row, column) of this launch
     int dbg;            // ablation switches of the ring kernel (tools/ab_ring.py --ablate): 1 no LDS-DMA in the K loop, 2 no MFMA, 4 no fragment reads, 8 no epilogue
 };
 
@@ -50,7 +51,9 @@ __device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v))
 
 // ---- epilogue shared by the tile kernels.  `lds` is a region of at least (waves * 32 * row bytes) that no wave reads
 //      as operand tiles any more; the caller has passed a workgroup barrier since the last operand read.
-template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false>
+// UP2: the tile's rows are pixels of the LOW-resolution grid [N, Hout, Wout]; row (n, y, x) is stored at pixel
+// (n, 2 y + up2_py, 2 x + up2_px) of the [N, 2 Hout, 2 Wout, Cout] output (sub-pixel form of nearest-x2 + conv3x3).
+template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
                                               int wm, int wn, int wid_s, int lane) {
     const int col = lane & 31, hi = lane >> 5;
@@ -227,7 +230,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
                 bool ok;
                 const uint32_t off = piece_off(it, ok);
-                if (ok) *(uint4*)(ybase + off * 2u) = o;
+                if constexpr (UP2) {
+                    const int f = it * 64 + lane;
+                    const int row = f / PIECES, co = nw0 + (f % PIECES) * 8;
+                    const long mrow = mb + (row < rows ? row : rows - 1);
+                    const long nimg = mrow / hw;
+                    const int rem = (int)(mrow - nimg * hw);
+                    const int yy = rem / p.Wout, xx = rem - yy * p.Wout;
+                    const long orow = (nimg * (2L * p.Hout) + 2 * yy + p.up2_py) * (2L * p.Wout) + 2 * xx + p.up2_px;
+                    if (ok) *(uint4*)((char*)yg + (orow * p.Cout + (co < cmax8 ? co : cmax8)) * 2) = o;
+                } else if (ok) *(uint4*)(ybase + off * 2u) = o;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
@@ -278,7 +290,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // pixel tile from the fabric for every tap: fetch / input = 8.9 - 14, profiles/r02_hbm_traffic.json).  The fp32 summation
 // order differs from the tap-major kernels.
 // ABL: ablation build (knob conv_dbg, tools/ab_ring.py --ablate): bit 1 of p.dbg skips the LDS-DMA of the K loop, bit 2 the MFMAs.
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false>
+// UP2 (4 taps): one output parity of nearest-x2-upsample + conv3x3 as a 2 x 2 convolution of the low-resolution input with
+// pre-summed weights (after the upsample every output parity sees only 2 x 2 distinct source pixels): tap (r, c) reads
+// source pixel (y + r + py - 1, x + c + px - 1); 4 / 9 of the MACs of the upsampled form.
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN * 16 > 200 ? 1 : 2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     const long bstride = (long)RPI * p.ntaps * p.Cin;
     int tap_p = 0, kk_p = 0;
     auto set_tap = [&](int tap) {
-        const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
+        const int dy = UP2 ? tap / 2 + p.up2_py : (p.ntaps == 9 ? tap / 3 : 1), dx = UP2 ? tap % 2 + p.up2_px : (p.ntaps == 9 ? tap % 3 : 1);
 #pragma unroll
         for (int i = 0; i < LDA; ++i) {
             int gy = (int)(pyx[i] & 0xffffu) * p.stride + dy - 1 + p.y_off;
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     static_assert((NT / 64) * 32 * (EPI == 1 ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
-    tile_epilogue<T, NT, TM, TN, EPI>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
+    tile_epilogue<T, NT, TM, TN, EPI, false, UP2>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
 
 // One 16-byte-per-lane LDS-DMA load issued from inline asm: `lds_dst` is the wave-uniform LDS byte address of the KiB the
@@ -1291,6 +1306,53 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     if (dtype == 1) return launch_conv<_Float16>(p, s);
     im360_set_error("conv_fwd: dtype %d unsupported", dtype);
     return IM360_ERR_UNSUPPORTED;
+}
+
+// nearest-x2 upsample + conv3x3 (pad 1) as four 2 x 2 convolutions of the low-resolution input, one per output parity:
+// x [N, Hin, Win, Cin] -> y [N, 2 Hin, 2 Win, Cout]; w4 = four packed 4-tap weights [4][CoutPad][4][Cin] in parity order
+// (py, px) = (0,0) (0,1) (1,0) (1,1), each the sum of the 3 x 3 taps that land on the same source pixel.
+extern "C" int im360_conv_up2_fwd(const void* x, const void* w4, const void* bias, void* y, int64_t N, int64_t Hin,
+                                  int64_t Win, int64_t Cin, int64_t Cout, int64_t wrap, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w4 && y, "conv_up2_fwd: null pointer");
+    IM360_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Cout > 0 && Cin > 0 && (Cin % 64) == 0, "conv_up2_fwd: Cin=%ld must be a positive multiple of 64", (long)Cin);
+    IM360_CHECK_ARG((Cout % 8) == 0, "conv_up2_fwd: Cout=%ld must be a multiple of 8", (long)Cout);
+    IM360_CHECK_ARG(2 * Hin <= 0xffff && 2 * Win <= 0xffff && N <= 0x7fffffffL, "conv_up2_fwd: image too large");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w4 % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 8) == 0,
+                    "conv_up2_fwd: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "conv_up2_fwd: dtype %d unsupported", dtype);
+    ConvParams p;
+    p.x = x; p.bias = bias; p.temb = nullptr; p.res = nullptr; p.y = y;
+    p.N = (int)N; p.Hin = (int)Hin; p.Win = (int)Win; p.Cin = (int)Cin;
+    p.Hout = (int)Hin; p.Wout = (int)Win; p.Cout = (int)Cout; p.ntaps = 4;          // the tile walks the LOW-resolution grid
+    p.stride = 1; p.up = 0; p.wrap = wrap ? 1 : 0; p.x_off = 0; p.y_off = 0; p.imgs_per_temb = 1;
+    p.M = N * Hin * Win;
+    p.dbg = 0;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_CONV, stream);
+    const long cout_pad = (Cout + 127) / 128 * 128;
+    const size_t esize = 2;
+    const bool big = Cout % 320 == 0 && ((p.M + 255) / 256) * (Cout / 320) >= 512;
+    for (int parity = 0; parity < 4; ++parity) {
+        p.w = (const char*)w4 + (size_t)parity * cout_pad * 4 * Cin * esize;
+        p.up2_py = parity >> 1;
+        p.up2_px = parity & 1;
+        if (big) {
+            constexpr int BM = 256, BN = 320;
+            p.tiles_n = (p.Cout + BN - 1) / BN;
+            p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+            if (dtype == 0) hipLaunchKernelGGL((conv_igemm_kernel<__bf16, 64, 4, 2, 2, 5, 0, false, false, true>), dim3((unsigned)p.nblocks), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<_Float16, 64, 4, 2, 2, 5, 0, false, false, true>), dim3((unsigned)p.nblocks), dim3(512), 0, s, p);
+        } else {
+            constexpr int BM = 128, BN = 128;
+            p.tiles_n = (p.Cout + BN - 1) / BN;
+            p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+            if (dtype == 0) hipLaunchKernelGGL((conv_igemm_kernel<__bf16, 64, 2, 2, 2, 2, 0, false, false, true>), dim3((unsigned)p.nblocks), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<_Float16, 64, 2, 2, 2, 2, 0, false, false, true>), dim3((unsigned)p.nblocks), dim3(256), 0, s, p);
+        }
+        IM360_CHECK_LAUNCH();
+    }
+    return IM360_OK;
 }
 
 extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
+    "im360_conv_up2_fwd": (_INT, [_PTR] * 4 + [_I64] * 6 + [_INT, _PTR]),
     "im360_remap_cubic_wrap_u8": (_INT, [_PTR] * 5 + [_I64] * 7 + [_PTR]),
     "im360_max_rect": (_INT, [_PTR, _I64, _I64, _PTR]),
     "im360_circular_pad_w": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
@@ -231,13 +232,47 @@ def pack_conv_weight(w, cin_pad=None):
     _dev(w)
     Cout, Cin, kh, kw = w.shape
     taps = kh * kw
-    assert taps in (1, 9)
+    assert taps in (1, 4, 9)
     cin_pad = cin_pad or ((Cin + 31) // 32) * 32
     cout_pad = ((Cout + 127) // 128) * 128
     out = torch.empty((cout_pad, taps, cin_pad), dtype=w.dtype, device=w.device)
     rc = lib().im360_pack_conv_weight(_p(w.contiguous()), _p(out), Cout, Cin, taps, cout_pad, cin_pad, _dt(w), _stream())
     _check(rc, "im360_pack_conv_weight")
     return out
+
+
+def up2_weights(w):
+    """[Cout, Cin, 3, 3] -> [4, Cout, Cin, 2, 2] (fp32): the taps of conv3x3-after-nearest-x2 that land on the same source
+    pixel, summed, per output parity (py, px) = (0,0) (0,1) (1,0) (1,1).  Row parity 0 reads source rows (y - 1, y) with
+    (k0, k1 + k2); parity 1 reads (y, y + 1) with (k0 + k1, k2); columns alike."""
+    w = w.detach().float()
+    rows = (torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2), torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], dim=2))   # [Cout, Cin, 2, 3]
+    out = []
+    for py in (0, 1):
+        r = rows[py]
+        for px in (0, 1):
+            out.append(torch.stack([r[..., 0], r[..., 1] + r[..., 2]], dim=-1) if px == 0 else torch.stack([r[..., 0] + r[..., 1], r[..., 2]], dim=-1))
+    return torch.stack(out)
+
+
+def pack_conv_up2_weight(w):
+    """Conv weight [Cout, Cin, 3, 3] (Cin % 64 == 0) -> the four packed 4-tap weights of ``conv_up2`` [4, CoutPad, 4, Cin]."""
+    _dev(w)
+    w4 = up2_weights(w).to(w.dtype)
+    return torch.stack([pack_conv_weight(w4[i].contiguous()) for i in range(4)]).contiguous()
+
+
+def conv_up2(x, w4_packed, cout, bias=None, wrap=False):
+    """nearest-x2 upsample + conv3x3 (pad 1, ``wrap``: circular along W) of x [N, Hin, Win, Cin] -> [N, 2 Hin, 2 Win, Cout],
+    as four 2 x 2 convolutions of the low-resolution input (4 / 9 of the MACs)."""
+    _dev(x, w4_packed, bias)
+    N, Hin, Win, Cin = x.shape
+    assert x.is_contiguous() and w4_packed.is_contiguous() and w4_packed.shape[0] == 4 and w4_packed.shape[2] == 4 and w4_packed.shape[3] == Cin
+    y = torch.empty((N, 2 * Hin, 2 * Win, cout), dtype=x.dtype, device=x.device)
+    rc = lib().im360_conv_up2_fwd(_p(x), _p(w4_packed), _p(bias), _p(y), N, Hin, Win, Cin, cout, int(wrap), _dt(x), _stream())
+    _check(rc, "im360_conv_up2_fwd")
+    _count("conv", 2.0 * N * 4 * Hin * Win * cout * Cin * 9, x.element_size() * (x.numel() + y.numel() + 9 * cout * Cin))
+    return y
 
 
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None,

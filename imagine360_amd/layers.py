@@ -48,6 +48,8 @@ class InflatedConv3d(nn.Conv2d):
     """Per-frame 2-D convolution (animatediff/models/resnet.py:19-27) on the HIP implicit-GEMM kernel.
     Parameters keep nn.Conv2d's names/shapes so reference checkpoints load unchanged."""
 
+    use_up2 = True          # class-wide switch: sub-pixel form of the upsample convolutions (False: A/B against the 9-tap form)
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._derived = DerivedCache()
@@ -65,6 +67,11 @@ class InflatedConv3d(nn.Conv2d):
         """x [N, H, W, Cin(+zero pad to a multiple of 32)] channels-last."""
         if x.shape[-1] != self.cin_padded:
             x = F.pad(x, (0, self.cin_padded - x.shape[-1]))
+        if up and self.use_up2 and self.in_channels % 64 == 0 and self.out_channels % 8 == 0 and res is None and temb is None \
+                and x_off == 0 and y_off == 0 and wout is None and self.stride[0] == 1:
+            # nearest x2 + conv3x3 as four 2x2 convolutions of the low-resolution input (pre-summed taps): 4/9 of the MACs
+            w4 = self._derived.get("w_up2", (self.weight,), lambda: kernels.pack_conv_up2_weight(self.weight))
+            return kernels.conv_up2(x, w4, self.out_channels, bias=self.bias, wrap=wrap)
         return kernels.conv2d(x, self.packed_weight(), self.out_channels, bias=self.bias, stride=self.stride[0],
                               up=up, wrap=wrap, x_off=x_off, wout=wout, temb=temb, imgs_per_temb=imgs_per_temb,
                               res=res, y_off=y_off)

@@ -96,6 +96,17 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
                    int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
                    int64_t imgs_per_temb, int dtype, void* stream);
 
+/* Nearest-x2 upsample followed by conv3x3 (pad 1; wrap: circular along W), computed as four 2 x 2 convolutions of the
+ * LOW-resolution input, one per output parity: after the upsample output pixel (2y + py, 2x + px) sees only the 2 x 2 source
+ * pixels (y + r + py - 1, x + c + px - 1), so the nine taps collapse into four pre-summed ones -- 4 / 9 of the MACs.
+ * x [N, Hin, Win, Cin] (Cin % 64 == 0) -> y [N, 2 Hin, 2 Win, Cout]; w4 = four im360_pack_conv_weight outputs (taps = 4,
+ * [CoutPad][4][Cin] each) back to back in parity order (0,0) (0,1) (1,0) (1,1).  The pre-summed weights are rounded to
+ * 16 bits once more than the reference's (a stated deviation).
+ * Replaces: Upsample3D = F.interpolate(scale 2, nearest) + InflatedConv3d (animatediff/models/resnet.py:71-114), incl. the
+ *   pano branch's pad_pano -> upsample -> unpad_pano sandwich (MVGenModel.py). */
+int im360_conv_up2_fwd(const void* x, const void* w4, const void* bias, void* y, int64_t N, int64_t Hin,
+                       int64_t Win, int64_t Cin, int64_t Cout, int64_t wrap, int dtype, void* stream);
+
 /* PyTorch conv weight [Cout, Cin, kh, kw] -> [CoutPad (mult. of 128)][kh*kw][CinPad (mult. of 32)]. */
 int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,
                            int64_t CoutPad, int64_t CinPad, int dtype, void* stream);

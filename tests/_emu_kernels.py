@@ -87,6 +87,28 @@ def pack_conv_weight(w, cin_pad=None):
     return out
 
 
+def pack_conv_up2_weight(w):
+    from imagine360_amd import kernels
+    w4 = kernels.up2_weights(w).to(w.dtype)
+    return torch.stack([pack_conv_weight(w4[i]) for i in range(4)])
+
+
+def conv_up2(x, w4_packed, cout, bias=None, wrap=False):
+    """Four 2x2 convolutions of the low-resolution input, one per output parity (same pre-summed weights as the kernel)."""
+    N, H, W, Cin = x.shape
+    g = x.permute(0, 3, 1, 2).float()
+    g = torch.cat([g[..., -1:], g, g[..., :1]], dim=-1) if wrap else F.pad(g, (1, 1, 0, 0))
+    g = F.pad(g, (0, 0, 1, 1))
+    y = torch.zeros(N, cout, 2 * H, 2 * W)
+    for parity in range(4):
+        py, px = parity >> 1, parity & 1
+        w = w4_packed[parity][:cout].reshape(cout, 2, 2, Cin).permute(0, 3, 1, 2).float()
+        y[:, :, py::2, px::2] = F.conv2d(g[:, :, py:py + H + 1, px:px + W + 1], w)
+    if bias is not None:
+        y = y + bias.float()[None, :, None, None]
+    return y.permute(0, 2, 3, 1).to(x.dtype).contiguous()
+
+
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None, temb=None,
            imgs_per_temb=1, res=None, y_off=0):
     N, Hin, Win, Cin = x.shape
@@ -171,7 +193,7 @@ def linear_geglu(x, w, b, inner):
 
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
-          "conv2d", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2", "pack_attn_bias"]
+          "conv2d", "pack_conv_up2_weight", "conv_up2", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2", "pack_attn_bias"]
 
 
 @contextlib.contextmanager

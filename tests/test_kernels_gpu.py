@@ -306,6 +306,33 @@ def test_conv3x3_256x320_tiles_addressing_modes(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,wrap", [(512, 16, 16, 64, 320, False),      # 256 x 320 tiles (512 of them)
+                                                 (32, 32, 64, 64, 640, True),        # panorama: circular along W
+                                                 (7, 5, 9, 128, 96, False),          # ragged, 128 x 128 tiles, Cout not a tile multiple
+                                                 (3, 4, 6, 64, 64, True)])
+def test_conv_up2_subpixel_upsample(dt, N, H, W, Cin, Cout, wrap):
+    """Upsample3D's nearest-x2 + conv3x3 as four 2 x 2 convolutions of the low-resolution input (im360_conv_up2_fwd,
+    pre-summed taps, 4 / 9 of the MACs) against the fp32 upsample + conv reference and against the 9-tap kernel path."""
+    g = torch.Generator().manual_seed(92)
+    x = q16(torch.randn(N, H, W, Cin, generator=g), dt)
+    w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
+    b = q16(torch.randn(Cout, generator=g) * 0.1, dt)
+    up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    if wrap:
+        ref = F.conv2d(F.pad(torch.cat([up[..., -1:], up, up[..., :1]], dim=-1), (0, 0, 1, 1)), w, b)
+    else:
+        ref = F.conv2d(up, w, b, padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    dx, dw, db = x.to(dt).cuda(), w.to(dt).cuda(), b.to(dt).cuda()
+    w4 = K.pack_conv_up2_weight(dw)
+    assert w4.shape == (4, (Cout + 127) // 128 * 128, 4, Cin)
+    out = K.conv_up2(dx, w4, Cout, bias=db, wrap=wrap)
+    assert out.shape == (N, 2 * H, 2 * W, Cout) and rel(out, ref) < TOL[dt]
+    old = K.conv2d(dx, K.pack_conv_weight(dw), Cout, bias=db, up=True, wrap=wrap)
+    assert rel(out, old.float().cpu()) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_linear_residual_through_gemm_kernel(dt):
     """Token counts large enough for layers.linear_residual to take the implicit-GEMM kernel (bias + residual in the
     epilogue) instead of hipBLASLt + add; both must agree with the fp32 reference."""

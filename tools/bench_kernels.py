@@ -110,6 +110,21 @@ def bench_conv(iters):
               f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
 
 
+def bench_up2(iters):
+    """Upsample3D convolutions: nearest-x2 folded into the 9-tap kernel's addressing vs four 2x2 convolutions of the
+    low-resolution input (sub-pixel form, 4/9 of the MACs).  TF/s are quoted on the 9-tap flop count for both."""
+    for name, N, H, W, C, wrap in [("pers L1->L0 640", 640, 16, 16, 640, False), ("pers L2->L1 1280", 640, 8, 8, 1280, False),
+                                   ("pers L3->L2 1280", 640, 4, 4, 1280, False), ("pano L1->L0 640", 32, 32, 64, 640, True),
+                                   ("pano L2->L1 1280", 32, 16, 32, 1280, True)]:
+        x, w, b = rn(N, H, W, C), rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)
+        wp, w4 = K.pack_conv_weight(w), K.pack_conv_up2_weight(w)
+        t9 = timeit(lambda: K.conv2d(x, wp, C, bias=b, up=True, wrap=wrap), iters)
+        t4 = timeit(lambda: K.conv_up2(x, w4, C, bias=b, wrap=wrap), iters)
+        fl = 2.0 * N * 4 * H * W * C * C * 9
+        print(f"up2   {name:18s} N={N:3d} {H}x{W} -> {2 * H}x{2 * W} C={C:4d}: 9-tap {t9 * 1e3:7.3f} ms {fl / t9 / 1e12:6.0f} TF/s | sub-pixel {t4 * 1e3:7.3f} ms "
+              f"({fl / t4 / 1e12:6.0f} TF/s equivalent, {t9 / t4:4.2f}x)")
+
+
 def bench_temporal(iters):
     for name, B, Fr, P, C in [("pers L0", 40, 16, 1024, 320), ("pano L0", 2, 16, 8192, 320), ("pers L1", 40, 16, 256, 640),
                               ("pers L2", 40, 16, 64, 1280), ("cfg4 pers L0 F48", 40, 48, 256, 320), ("cfg4 pano L0 F48", 2, 48, 2048, 320),
@@ -232,7 +247,7 @@ if __name__ == "__main__":
     if "--iters" in sys.argv:
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
         args = [a for a in args if a != str(iters)]
-    which = args or ["attn", "conv", "temporal", "ln", "gn", "linear", "geglu_fused"]
+    which = args or ["attn", "conv", "up2", "temporal", "ln", "gn", "linear", "geglu_fused"]
     torch.set_grad_enabled(False)
     for w in which:
         globals()["bench_" + w](iters)
