@@ -21,12 +21,14 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Elem;
 template <> struct Elem<__bf16> {
     typedef bf16x8 vec8;
+    static constexpr uint32_t ones2 = 0x3F803F80u;      // (1.0, 1.0)
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Elem<_Float16> {
     typedef f16x8 vec8;
+    static constexpr uint32_t ones2 = 0x3C003C00u;
     static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
@@ -62,6 +64,17 @@ template <typename T>
 __device__ __forceinline__ u32x2 lds_read_tr16(const T* lds_ptr) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lds_ptr));
+}
+
+// c + a.lo * b.lo + a.hi * b.hi on two packed 16-bit pairs, fp32 accumulate: one v_dot2c_f32_{bf16,f16}, no unpacking
+template <typename T> __device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c);
+template <> __device__ __forceinline__ float dot2_acc<__bf16>(uint32_t a, uint32_t b, float c) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2_acc<_Float16>(uint32_t a, uint32_t b, float c) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
 }
 
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }

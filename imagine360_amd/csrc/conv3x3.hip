@@ -22,6 +22,8 @@
 // swizzle that keeps ds_read_b128 fragment reads conflict-free is applied on the source side (the DMA
 // destination is lane-linear).  Double-buffered LDS, one barrier per K-step: step s+1 streams in under
 // the MFMAs of step s.
+#include <string.h>
+
 #include "common.h"
 
 namespace im360 {
@@ -38,7 +40,27 @@ struct ConvParams {
     int halo_r, halo_seg, halo_pw, halo_p;      // halo kernel: output rows per tile, rows per image segment, patch width / pixels
     int up2_py, up2_px; // UP2 kernels: output parity (row, column) of this launch
     int dbg;            // ablation switches of the ring kernel (tools/ab_ring.py --ablate): 1 no LDS-DMA in the K loop, 2 no MFMA, 4 no fragment reads, 8 no epilogue
+    // 1x1 convolution of a channel concatenation that is never materialised: input channels [0, Cin1) come from x
+    // (pixel stride Cin1), channels [Cin1, Cin) from x2 (pixel stride Cin - Cin1); x2 == nullptr: one source
+    const void* x2; int Cin1;
+    // token-major linears only.  rs_out: the epilogue also writes, per output row and per 160-column wave slice, (sum,
+    // sum of squares) of the stored 16-bit values: fp32 [M][Cout / 160][2] -- the LayerNorm statistics of the rows for a
+    // consumer GEMM with the normalisation folded in (EPI 3 / 4), which reads them through rs_in ([M][rs_p][2]):
+    //   y = rstd_r * (x W'^T - mu_r * c1) + c2 (+ tab[(r / tab_div) % tab_mod])      W' = gamma (.) W
+    float* rs_out; const float* rs_in; int rs_p; float ln_eps, ln_invc;
+    const float* ln_c1; const float* ln_c2; const float* ln_tab; int tab_div, tab_mod;
+    // persistent tile walk of the ring kernel: the cout tiles are split into `ngroups` groups, each walked by 8 / ngroups
+    // XCDs over all pixel tiles (keeps one group's weights resident in those XCDs' L2s)
+    int ngroups;
 };
+
+// ConvParams with the optional members cleared
+static inline ConvParams conv_params_zero() {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.ngroups = 1;
+    return p;
+}
 
 
 // 16 bytes of zeros that out-of-image taps are pointed at (LDS-DMA loads cannot zero-fill by themselves)
@@ -67,7 +89,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
     // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
     // different bank pairs (checked exhaustively for 320- and 128-byte rows).  The row-major side reads whole pieces.
     auto piece_xor = [](int row, int rowb) { return rowb == 128 ? (row & 7) : ((row >> 1) & 3); };
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 || EPI == 4) {
         // GEGLU epilogue (token-major linear only): the packed weight rows alternate 32 value rows / 32 gate rows of the
         // same output channels, so accumulators (2i, 2i+1) hold value and gate of one channel in the same lane and
         // register: out = (value + b) * gelu(gate + b), half as many columns as the GEMM is wide.
@@ -82,7 +104,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         const T* gb = bias ? bias : (const T*)g_zero_chunk;      // unconditional bias loads (see the plain epilogue)
         const int gbmul = bias ? 1 : 0;
         // the biases of this lane's channels, unpacked once for all TM pixel blocks (the K-loop operand registers are free)
-        f32x2 bv[TN / 2][4][2], bt[TN / 2][4][2];
+        f32x2 bv[EPI == 1 ? TN / 2 : 1][4][2], bt[EPI == 1 ? TN / 2 : 1][4][2];
+        if constexpr (EPI == 1) {
 #pragma unroll
         for (int i = 0; i < TN / 2; ++i)
 #pragma unroll
@@ -94,9 +117,28 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 bt[i][g][0] = f32x2{unpack_lo<T>(wg.x), unpack_hi<T>(wg.x)};
                 bt[i][g][1] = f32x2{unpack_lo<T>(wg.y), unpack_hi<T>(wg.y)};
             }
+        }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const long mb = m0 + wm * (TM * 32) + b * 32;
+            // EPI 4: LayerNorm folded into the projection -- the accumulators hold x W'^T of the RAW rows (W' = gamma (.) W);
+            // with the row's mean / rstd from the producer's statistics, value = rstd * (acc - mu * c1) + c2 (fp32 vectors in
+            // packed row order: c1 = row sums of W', c2 = W beta + bias)
+            f32x2 MU = {0.f, 0.f}, RS = {1.f, 1.f};
+            if constexpr (EPI == 4) {
+                const long mrow = mb + col < p.M ? mb + col : p.M - 1;
+                float ss = 0.f, qq = 0.f;
+                for (int j = 0; j < p.rs_p; ++j) {
+                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
+                    ss += v.x;
+                    qq += v.y;
+                }
+                const float mu = ss * p.ln_invc;
+                const float var = fmaxf(qq * p.ln_invc - mu * mu, 0.f);
+                const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+                MU = f32x2{mu, mu};
+                RS = f32x2{rstd, rstd};
+            }
 #pragma unroll
             for (int i = 0; i < TN / 2; ++i)
 #pragma unroll
@@ -105,10 +147,20 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     //  one rounding less on the way to the fp32 oracle)
                     f32x2 v01 = {acc[2 * i][b][4 * g], acc[2 * i][b][4 * g + 1]}, v23 = {acc[2 * i][b][4 * g + 2], acc[2 * i][b][4 * g + 3]};
                     f32x2 t01 = {acc[2 * i + 1][b][4 * g], acc[2 * i + 1][b][4 * g + 1]}, t23 = {acc[2 * i + 1][b][4 * g + 2], acc[2 * i + 1][b][4 * g + 3]};
+                    if constexpr (EPI == 4) {
+                        const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows
+                        const f32x4 k1v = *(const f32x4*)(p.ln_c1 + rv), k2v = *(const f32x4*)(p.ln_c2 + rv);
+                        const f32x4 k1g = *(const f32x4*)(p.ln_c1 + rg), k2g = *(const f32x4*)(p.ln_c2 + rg);
+                        v01 = (v01 - MU * k1v.xy) * RS + k2v.xy;
+                        v23 = (v23 - MU * k1v.zw) * RS + k2v.zw;
+                        t01 = (t01 - MU * k1g.xy) * RS + k2g.xy;
+                        t23 = (t23 - MU * k1g.zw) * RS + k2g.zw;
+                    } else {
                     v01 += bv[i][g][0];
                     v23 += bv[i][g][1];
                     t01 += bt[i][g][0];
                     t23 += bt[i][g][1];
+                    }
                     v01 *= gelu_erf_pk(t01);
                     v23 *= gelu_erf_pk(t23);
                     uint2 o;
@@ -168,6 +220,25 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             char* ybase = (char*)(yg + mb * p.Cout);
             const long m = mb + (col < rows ? col : rows - 1);
             const uint32_t toff = (uint32_t)((m / hw) / p.imgs_per_temb) * (uint32_t)p.Cout;   // temb row of this lane's pixel
+            // EPI 3: LayerNorm folded into the projection (see ConvParams): mean / rstd of this lane's row from the producer's
+            // per-slice (sum, sum of squares); the optional table adds row group (m / tab_div) % tab_mod's fp32 vector
+            float ln_mu = 0.f, ln_rstd = 1.f;
+            const float* ln_trow = (const float*)zsrc;
+            uint32_t ln_tmul = 0u;
+            if constexpr (EPI == 3) {
+                float ss = 0.f, qq = 0.f;
+                for (int j = 0; j < p.rs_p; ++j) {
+                    const f32x2 v = *(const f32x2*)(p.rs_in + (m * p.rs_p + j) * 2);
+                    ss += v.x;
+                    qq += v.y;
+                }
+                ln_mu = ss * p.ln_invc;
+                ln_rstd = __builtin_amdgcn_rsqf(fmaxf(qq * p.ln_invc - ln_mu * ln_mu, 0.f) + p.ln_eps);
+                if (p.ln_tab) {
+                    ln_trow = p.ln_tab + ((m / p.tab_div) % p.tab_mod) * (long)p.Cout;
+                    ln_tmul = 1u;
+                }
+            }
             // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
             // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
             constexpr int NIT = (32 * PIECES) / 64, NIT1 = NIT / 2;
@@ -189,13 +260,39 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             __builtin_amdgcn_sched_barrier(0);    // (hipcc would hoist every load of the block up here and spill)
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
+                if constexpr (EPI == 3) {
+                    // two register groups at a time: the fp32 vectors of four would not fit next to the accumulators
+#pragma unroll
+                    for (int gh = 0; gh < 2; ++gh) {
+                        f32x4 k1[2], k2[2], kt[2];
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const int co = nw0 + a * 32 + 8 * (2 * gh + g2) + 4 * hi;
+                            const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
+                            k1[g2] = *(const f32x4*)(p.ln_c1 + cc);
+                            k2[g2] = *(const f32x4*)(p.ln_c2 + cc);
+                            kt[g2] = *(const f32x4*)(ln_trow + cc * ln_tmul);
+                        }
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            const int g = 2 * gh + g2;
+                            float f[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) f[j] = (acc[a][b][4 * g + j] - ln_mu * k1[g2][j]) * ln_rstd + (k2[g2][j] + kt[g2][j]);
+                            uint2 o;
+                            o.x = pack2<T>(f[0], f[1]);
+                            o.y = pack2<T>(f[2], f[3]);
+                            *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
+                        }
+                    }
+                } else {
                 uint2 wb[4], wt[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = nw0 + a * 32 + 8 * g + 4 * hi;
                     const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
                     wb[g] = *(const uint2*)(bsrc + cc * bmul);
-                    if constexpr (EPI != 2) wt[g] = *(const uint2*)(tsrc + (toff + cc) * tmul);      // (token-major linears have no temb)
+                    if constexpr (EPI == 0) wt[g] = *(const uint2*)(tsrc + (toff + cc) * tmul);      // (token-major linears have no temb)
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -203,13 +300,14 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
                     f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
-                    if constexpr (EPI != 2) {
+                    if constexpr (EPI == 0) {
                         f[0] += unpack_lo<T>(wt[g].x); f[1] += unpack_hi<T>(wt[g].x); f[2] += unpack_lo<T>(wt[g].y); f[3] += unpack_hi<T>(wt[g].y);
                     }
                     uint2 o;
                     o.x = pack2<T>(f[0], f[1]);
                     o.y = pack2<T>(f[2], f[3]);
                     *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -230,6 +328,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
                 bool ok;
                 const uint32_t off = piece_off(it, ok);
+                if constexpr (EPI == 5) {
+                    // row statistics of the STORED values (what a LayerNorm of this tensor would read): this piece's
+                    // (sum, sum of squares) parked in its own staging slot, collected per row after the store rounds
+                    float ss = 0.f, qq = 0.f;
+                    ss = dot2_acc<T>(o.x, Elem<T>::ones2, ss); qq = dot2_acc<T>(o.x, o.x, qq);
+                    ss = dot2_acc<T>(o.y, Elem<T>::ones2, ss); qq = dot2_acc<T>(o.y, o.y, qq);
+                    ss = dot2_acc<T>(o.z, Elem<T>::ones2, ss); qq = dot2_acc<T>(o.z, o.z, qq);
+                    ss = dot2_acc<T>(o.w, Elem<T>::ones2, ss); qq = dot2_acc<T>(o.w, o.w, qq);
+                    *(f32x2*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4)) = f32x2{ss, qq};
+                }
                 if constexpr (UP2) {
                     const int f = it * 64 + lane;
                     const int row = f / PIECES, co = nw0 + (f % PIECES) * 8;
@@ -240,6 +348,27 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     const long orow = (nimg * (2L * p.Hout) + 2 * yy + p.up2_py) * (2L * p.Wout) + 2 * xx + p.up2_px;
                     if (ok) *(uint4*)((char*)yg + (orow * p.Cout + (co < cmax8 ? co : cmax8)) * 2) = o;
                 } else if (ok) *(uint4*)(ybase + off * 2u) = o;
+            }
+            if constexpr (EPI == 5) {
+                // two lanes per row add up the row's pieces in a fixed order (deterministic, unlike atomics) and write the
+                // wave slice's (sum, sum of squares) of the row: rs_out[row][Cout / (32 TN)][2]
+                static_assert(PIECES % 2 == 0, "two lanes per row");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int row = lane >> 1, half = lane & 1;
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int j = 0; j < PIECES / 2; ++j) {
+                    const int pc = half * (PIECES / 2) + j;
+                    const f32x2 v = *(const f32x2*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
+                    ss += v.x;
+                    qq += v.y;
+                }
+                ss += __shfl_xor(ss, 1);
+                qq += __shfl_xor(qq, 1);
+                const int slices = p.Cout / (TN * 32);
+                if (half == 0 && row < rows)
+                    *(f32x2*)(p.rs_out + ((mb + row) * slices + nw0 / (TN * 32)) * 2) = f32x2{ss, qq};
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
@@ -368,8 +497,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     const T* bptr = wg + (long)(n0 + srow) * p.ntaps * p.Cin + pd8;
     const long bstride = (long)RPI * p.ntaps * p.Cin;
     int tap_p = 0, kk_p = 0;
-    auto set_tap = [&](int tap) {
+    // two sources (p.x2, 1x1 only): `second` = the channels past Cin1, read from x2 with its own pixel stride
+    const int ksteps_src1 = p.x2 ? p.Cin1 / BK : -1;
+    auto set_tap = [&](int tap, bool second = false) {
         const int dy = UP2 ? tap / 2 + p.up2_py : (p.ntaps == 9 ? tap / 3 : 1), dx = UP2 ? tap % 2 + p.up2_px : (p.ntaps == 9 ? tap % 3 : 1);
+        const T* src = second ? (const T*)p.x2 : xg;
+        const int cs = p.x2 ? (second ? p.Cin - p.Cin1 : p.Cin1) : p.Cin;       // channels per pixel of the source tensor
 #pragma unroll
         for (int i = 0; i < LDA; ++i) {
             int gy = (int)(pyx[i] & 0xffffu) * p.stride + dy - 1 + p.y_off;
@@ -381,8 +514,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
                 ok = ok && gx >= 0 && gx < Wc;
             }
             const int sy = gy >> p.up, sx = gx >> p.up;
-            const long off = ok ? (((long)(pnv[i] & 0x7fffffffu) * p.Hin + sy) * p.Win + sx) * p.Cin + pd8 : 0;
-            aptr[i] = ok ? xg + off : zero;
+            const long off = ok ? (((long)(pnv[i] & 0x7fffffffu) * p.Hin + sy) * p.Win + sx) * cs + pd8 : 0;
+            aptr[i] = ok ? src + off : zero;
             amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
         }
     };
@@ -447,6 +580,8 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
             if (++kk_p == ksteps_per_tap) {
                 kk_p = 0;
                 if (++tap_p < p.ntaps) set_tap(tap_p);
+            } else if (kk_p == ksteps_src1) {
+                set_tap(tap_p, true);           // the concatenation's second tensor takes over (weights just keep advancing)
             }
         }
     };
@@ -529,7 +664,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
         if (ILV && more) stage_advance();
     }
 
-    static_assert((NT / 64) * 32 * (EPI == 1 ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
+    static_assert((NT / 64) * 32 * ((EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
     tile_epilogue<T, NT, TM, TN, EPI, false, UP2>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
@@ -573,7 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int LDB = (BN * CPR) / NT;                  // 2 full rounds of weights ...
     constexpr bool B_TAIL = (BN * CPR) % NT != 0;         // ... + half a round (waves 0..3) when BN = 320
     static_assert((BM * CPR) % NT == 0 && ((BN * CPR) % NT == 0 || (BN * CPR) % NT == NT / 2), "staging pattern");
-    constexpr int EPI_ROWB = EPI == 1 ? (TN / 2) * 64 : TN * 64;
+    constexpr int EPI_ROWB = (EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
     constexpr int LDS_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -591,10 +726,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     // persistent tile walk: block b sits on XCD b % 8 (observed dispatch order; only speed depends on it).  Round `it`
     // covers gridDim.x consecutive logical tiles, XCD x takes the x-th eighth of them: the tiles in flight on one XCD are
     // neighbours (same pixel rows / neighbouring cout tiles), the chip as a whole works on one contiguous range.
-    const long ntiles = p.nblocks;
+    // Cout groups (p.ngroups = 1, 2, 4 or 8, dividing tiles_n): group g's cout tiles are walked by XCDs g * XG .. g * XG + XG - 1
+    // only, over all pixel tiles -- with few large weight tiles (the 640 -> 5120 GEGLU projection: 20 tiles of 327 KB) one
+    // group's weights then stay in those XCDs' L2s instead of being re-fetched by every XCD in every round.
     const int per_xcd = gridDim.x / 8;
-    const long tile_first = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const long tile_step = gridDim.x;
+    const int xg_n = 8 / p.ngroups, tn_g = p.tiles_n / p.ngroups;
+    const int grp = (blockIdx.x % 8) / xg_n;
+    const long ntiles = p.nblocks / p.ngroups;              // tiles of one group, index j = pixel tile * tn_g + local cout tile
+    const long tile_first = (long)((blockIdx.x % 8) % xg_n) * per_xcd + blockIdx.x / 8;
+    const long tile_step = (long)xg_n * per_xcd;
+    auto tile_m0 = [&](long j) { return (j / tn_g) * BM; };
+    auto tile_n0 = [&](long j) { return (grp * tn_g + (int)(j % tn_g)) * BN; };
 
     constexpr int RPI = NT / CPR;               // 128 tile rows between a thread's consecutive chunks
     const int srow = tid / CPR;
@@ -629,8 +771,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
     };
     auto init_tile = [&](long tile) {
-        const long m0 = (tile / p.tiles_n) * BM;
-        const int n0 = (int)(tile % p.tiles_n) * BN;
+        const long m0 = tile_m0(tile);
+        const int n0 = tile_n0(tile);
         bptr = wg + (long)(n0 + srow) * p.ntaps * p.Cin + pd8;
         tap_p = 0;
         kk_p = 0;
@@ -721,8 +863,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     issue(0);
     if (nph > 1) issue(1);
     for (;;) {
-        const long m0 = (tile / p.tiles_n) * BM;
-        const int n0 = (int)(tile % p.tiles_n) * BN;
+        const long m0 = tile_m0(tile);
+        const int n0 = tile_n0(tile);
         // phase 2 goes into a slot the previous tile's epilogue used: every wave has to be out of it
         asm volatile("s_barrier" ::: "memory");
         if (nph > 2) issue(2);
@@ -1187,12 +1329,30 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     p.dbg = knob(KNOB_CONV_DBG);
     const long want = (p.nblocks + 7) / 8 * 8;
     const unsigned grid = (unsigned)(want < ncu ? want : ncu);
+    // cout groups of the tile walk (see the kernel): the fewest of 1 / 2 / 4 / 8 that divide tiles_n and bring one group's
+    // weights under ~3.4 MB of the XCD's 4 MB L2 (knob ring_groups: 0 = this rule, else forced when it divides tiles_n)
+    {
+        const long wbytes = (long)p.tiles_n * BN * p.ntaps * p.Cin * 2;
+        int ng = 1;
+        const int force = knob(KNOB_RING_GROUPS);
+        if (force > 0) {
+            if ((force == 2 || force == 4 || force == 8) && p.tiles_n % force == 0) ng = force;
+        } else {
+            while (ng < 8 && wbytes / ng > 3400000L && p.tiles_n % (2 * ng) == 0) ng *= 2;
+            if (wbytes / ng > 3400000L) ng = 1;          // no split brings a group under the budget: keep the plain walk
+        }
+        p.ngroups = grid >= 8u * ng ? ng : 1;
+    }
     // variant (knob conv_ring): 1 = asm LDS-DMA, pieces interleaved with the MFMAs (default); 2 = builtin LDS-DMA, plain ring;
     // 3 = asm LDS-DMA, plain ring; 4 = asm LDS-DMA, staggered wave groups
+    if constexpr (EPI >= 3) {                   // LayerNorm-folded / statistics-writing epilogues: the default pipeline only
+        hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+    } else {
     if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false, 0>), dim3(grid), dim3(512), 0, stream, p);
     else if (variant == 3) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 0>), dim3(grid), dim3(512), 0, stream, p);
     else if (variant == 4) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 1>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+    }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
@@ -1292,7 +1452,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                     ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)temb % 8) == 0,
                     "conv_fwd: misaligned pointer");
-    ConvParams p;
+    ConvParams p = conv_params_zero();
     p.x = x; p.w = w_packed; p.bias = bias; p.temb = temb; p.res = res; p.y = y;
     p.N = (int)N; p.Hin = (int)Hin; p.Win = (int)Win; p.Cin = (int)Cin;
     p.Hout = (int)Hout; p.Wout = (int)Wout; p.Cout = (int)Cout; p.ntaps = (int)ntaps;
@@ -1321,7 +1481,7 @@ extern "C" int im360_conv_up2_fwd(const void* x, const void* w4, const void* bia
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w4 % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 8) == 0,
                     "conv_up2_fwd: misaligned pointer");
     IM360_CHECK_ARG(dtype == 0 || dtype == 1, "conv_up2_fwd: dtype %d unsupported", dtype);
-    ConvParams p;
+    ConvParams p = conv_params_zero();
     p.x = x; p.bias = bias; p.temb = nullptr; p.res = nullptr; p.y = y;
     p.N = (int)N; p.Hin = (int)Hin; p.Win = (int)Win; p.Cin = (int)Cin;
     p.Hout = (int)Hin; p.Wout = (int)Win; p.Cout = (int)Cout; p.ntaps = 4;          // the tile walks the LOW-resolution grid
@@ -1363,7 +1523,7 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     IM360_CHECK_ARG(I > 0 && (I % 128) == 0, "linear_geglu: I=%ld must be a positive multiple of 128", (long)I);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                     ((uintptr_t)bias_packed % 8) == 0, "linear_geglu: misaligned pointer");
-    ConvParams p;
+    ConvParams p = conv_params_zero();
     p.x = x; p.w = w_packed; p.bias = bias_packed; p.temb = nullptr; p.res = nullptr; p.y = y;
     p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)(2 * I); p.ntaps = 1;
     p.stride = 1; p.up = 0; p.wrap = 0; p.x_off = 0; p.y_off = 0; p.imgs_per_temb = 1;
@@ -1384,6 +1544,110 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     if (dtype == 1) return launch_conv_t<_Float16, 4, 2, 2, 4, 1>(p, s);
     im360_set_error("linear_geglu: dtype %d unsupported", dtype);
     return IM360_ERR_UNSUPPORTED;
+}
+
+// 1x1 convolution of the channel concatenation [xa | xb] that is never materialised (the skip connections of the decoder:
+// src/models/MVGenModel.py:407, 415, 431, 437 concatenate, animatediff/models/resnet.py:248-251 runs conv_shortcut on the
+// result): xa [N, H, W, C1], xb [N, H, W, C2], w_packed [CoutPad][1][C1 + C2] -> y [N, H, W, Cout] (+ bias, + res).
+extern "C" int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void* w_packed, const void* bias, const void* res,
+                                     void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t Cout,
+                                     int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(xa && xb && w_packed && y, "conv1x1_cat_fwd: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0, "conv1x1_cat_fwd: empty problem");
+    IM360_CHECK_ARG(C1 > 0 && C2 > 0 && (C1 % 64) == 0 && (C2 % 64) == 0, "conv1x1_cat_fwd: C1=%ld, C2=%ld must be positive multiples of 64", (long)C1, (long)C2);
+    IM360_CHECK_ARG(H <= 0xffff && W <= 0xffff && N <= 0x7fffffffL, "conv1x1_cat_fwd: H, W must fit 16 bits");
+    IM360_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0, "conv1x1_cat_fwd: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "conv1x1_cat_fwd: dtype %d unsupported", dtype);
+    ConvParams p = conv_params_zero();
+    p.x = xa; p.x2 = xb; p.Cin1 = (int)C1; p.w = w_packed; p.bias = bias; p.res = res; p.y = y;
+    p.N = (int)N; p.Hin = (int)H; p.Win = (int)W; p.Cin = (int)(C1 + C2);
+    p.Hout = (int)H; p.Wout = (int)W; p.Cout = (int)Cout; p.ntaps = 1;
+    p.stride = 1; p.imgs_per_temb = 1;
+    p.M = N * H * W;
+    ProfScope prof(PROF_CONV, stream);
+    return dtype == 0 ? launch_conv<__bf16>(p, (hipStream_t)stream) : launch_conv<_Float16>(p, (hipStream_t)stream);
+}
+
+// Token-major Linear y[M, N] = x[M, K] w^T + bias (+ res) on the persistent ring kernel (N % 320 == 0, K % 32 == 0), with
+// optional per-row statistics of the stored output: rowstats [M][N / 160][2] fp32 = (sum, sum of squares) of each
+// 160-column slice -- what a following LayerNorm needs, so that the consumer can fold the normalisation into its GEMM
+// (im360_linear_ln_fwd / im360_linear_geglu_ln) and the LayerNorm pass over the activations disappears.
+// Replaces: nn.Linear + residual add feeding nn.LayerNorm, animatediff/models/attention.py:461-508, motion_module.py:230-258.
+extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y,
+                                void* rowstats, int64_t M, int64_t K, int64_t N, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w_packed && y, "linear_fwd: null pointer");
+    IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_fwd: K=%ld must be a positive multiple of 32", (long)K);
+    IM360_CHECK_ARG(N > 0 && (N % 320) == 0, "linear_fwd: N=%ld must be a positive multiple of 320", (long)N);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                    ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_fwd: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_fwd: dtype %d unsupported", dtype);
+    ConvParams p = conv_params_zero();
+    p.x = x; p.w = w_packed; p.bias = bias; p.res = res; p.y = y; p.rs_out = (float*)rowstats;
+    p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)N; p.ntaps = 1;
+    p.stride = 1; p.imgs_per_temb = 1;
+    p.M = M;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GEMM, stream);
+    const int v = knob(KNOB_CONV_RING) >= 1 && knob(KNOB_CONV_RING) <= 4 ? knob(KNOB_CONV_RING) : 1;
+    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, 1);
+    return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);
+}
+
+// LayerNorm folded into the consuming Linear: x are the RAW rows, w_packed = pack(gamma (.) W), and with the rows'
+// statistics from the producer (rowstats [M][rs_p][2], im360_linear_fwd)
+//   y[r] = rstd_r * (x[r] w^T - mu_r * c1) + c2 (+ tab[(r / tab_div) % tab_mod])
+// c1[n] = sum_k w'[n][k] (of the ROUNDED 16-bit w'), c2 = W beta + bias, tab (optional, fp32 [tab_mod][N]) e.g. the
+// motion module's frame positional encoding pushed through the projection.  All fp32 vectors.  N % 320 == 0, K % 32 == 0.
+// Replaces: nn.LayerNorm -> nn.Linear (to_q / fused qkv), animatediff/models/attention.py:470-488, motion_module.py:236-250.
+extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+                                   int64_t rs_p, float eps, const void* tab, int64_t tab_div, int64_t tab_mod, void* y,
+                                   int64_t M, int64_t K, int64_t N, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w_packed && c1 && c2 && rowstats && y, "linear_ln_fwd: null pointer");
+    IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_ln_fwd: K=%ld must be a positive multiple of 32", (long)K);
+    IM360_CHECK_ARG(N > 0 && (N % 320) == 0, "linear_ln_fwd: N=%ld must be a positive multiple of 320", (long)N);
+    IM360_CHECK_ARG(rs_p > 0 && rs_p <= 64, "linear_ln_fwd: rs_p=%ld out of range", (long)rs_p);
+    IM360_CHECK_ARG(!tab || (tab_div > 0 && tab_mod > 0), "linear_ln_fwd: tab_div, tab_mod must be positive");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)c1 % 16) == 0 &&
+                    ((uintptr_t)c2 % 16) == 0 && ((uintptr_t)tab % 16) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_ln_fwd: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_ln_fwd: dtype %d unsupported", dtype);
+    ConvParams p = conv_params_zero();
+    p.x = x; p.w = w_packed; p.y = y;
+    p.rs_in = (const float*)rowstats; p.rs_p = (int)rs_p; p.ln_eps = eps; p.ln_invc = 1.0f / (float)K;
+    p.ln_c1 = (const float*)c1; p.ln_c2 = (const float*)c2; p.ln_tab = (const float*)tab;
+    p.tab_div = tab ? (int)tab_div : 1; p.tab_mod = tab ? (int)tab_mod : 1;
+    p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)N; p.ntaps = 1;
+    p.stride = 1; p.imgs_per_temb = 1;
+    p.M = M;
+    ProfScope prof(PROF_GEMM, stream);
+    return dtype == 0 ? launch_ring_t<__bf16, 5, 3, true>(p, (hipStream_t)stream, 1) : launch_ring_t<_Float16, 5, 3, true>(p, (hipStream_t)stream, 1);
+}
+
+// LayerNorm folded into the fused GEGLU projection (im360_linear_geglu with w_packed = pack_geglu(gamma (.) W) and the
+// fp32 vectors c1, c2 in the same interleaved row order): out = v * gelu(g), (v | g) = rstd * (x w^T - mu c1) + c2.
+// Replaces: nn.LayerNorm -> GEGLU, animatediff/models/attention.py:503-506, motion_module.py:255-257.
+extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+                                     int64_t rs_p, float eps, void* y, int64_t M, int64_t K, int64_t I, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && w_packed && c1 && c2 && rowstats && y, "linear_geglu_ln: null pointer");
+    IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_geglu_ln: K=%ld must be a positive multiple of 32", (long)K);
+    IM360_CHECK_ARG(I > 0 && (I % 128) == 0, "linear_geglu_ln: I=%ld must be a positive multiple of 128", (long)I);
+    IM360_CHECK_ARG(rs_p > 0 && rs_p <= 64, "linear_geglu_ln: rs_p=%ld out of range", (long)rs_p);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)c1 % 16) == 0 &&
+                    ((uintptr_t)c2 % 16) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_geglu_ln: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_geglu_ln: dtype %d unsupported", dtype);
+    ConvParams p = conv_params_zero();
+    p.x = x; p.w = w_packed; p.y = y;
+    p.rs_in = (const float*)rowstats; p.rs_p = (int)rs_p; p.ln_eps = eps; p.ln_invc = 1.0f / (float)K;
+    p.ln_c1 = (const float*)c1; p.ln_c2 = (const float*)c2;
+    p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)(2 * I); p.ntaps = 1;
+    p.stride = 1; p.imgs_per_temb = 1;
+    p.M = M;
+    ProfScope prof(PROF_GEMM, stream);
+    return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, 1) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, 1);
 }
 
 extern "C" int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,

@@ -18,9 +18,12 @@ namespace im360 {
 
 // ---- pass 1 -----------------------------------------------------------------------------------
 // grid (S, N), 256 threads.  partial[n][s][0][c] = sum w*x, partial[n][s][1][c] = sum w*x^2
+// Channel concatenations that are never materialised (the decoder's skip connections): the kernel is launched once per
+// source tensor; C = channels of THIS tensor (its pixel stride), Ct = channels of the concatenation (the layout of
+// `partial`), coff = where this tensor's channels start in it.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
-                                                          int HW, int W, int C, int pad, int S) {
+                                                          int HW, int W, int C, int pad, int S, int Ct, int coff) {
     __shared__ float red[256 * 16];
     const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int nch = C >> 3;
@@ -73,11 +76,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
             for (int l = 1; l < lanes; ++l)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] += red[(l * ncp + cc) * 16 + e];
-            float* dst = partial + ((long)(n * S + s) * 2) * C + (c0 + cc) * 8;
+            float* dst = partial + ((long)(n * S + s) * 2) * Ct + coff + (c0 + cc) * 8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 dst[e] = acc[e];
-                dst[C + e] = acc[8 + e];
+                dst[Ct + e] = acc[8 + e];
             }
         }
     }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, T* __restrict__ y,
-                                                        int H, int W, int C, int pad, int act, int S) {
+                                                        int H, int W, int C, int pad, int act, int S, int Ct, int coff) {
     const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int nch = C >> 3;
     const int Wo = W + 2 * pad;
@@ -132,15 +135,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int pps = (HWo + S - 1) / S;
     const int pix0 = s * pps, pix1 = min(HWo, pix0 + pps);
     const T* xb = x + (long)n * H * W * C;
-    T* yb = y + (long)n * HWo * C;
+    T* yb = y + (long)n * HWo * Ct + coff;         // (C, Ct, coff as in gn_partial_kernel: y and scale / shift span the concatenation)
     for (int c0 = 0; c0 < nch; c0 += 256) {
         const int ncp = min(256, nch - c0);
         const int lanes = 256 / ncp;
         const int cc = tid % ncp, pl = tid / ncp;
         if (pl >= lanes) continue;
         float sc[8], sh[8];
-        const float* sp = scale + (long)n * C + (c0 + cc) * 8;
-        const float* hp = shift + (long)n * C + (c0 + cc) * 8;
+        const float* sp = scale + (long)n * Ct + coff + (c0 + cc) * 8;
+        const float* hp = shift + (long)n * Ct + coff + (c0 + cc) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             sc[e] = sp[e];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                 float v = f[e] * sc[e] + sh[e];
                 f[e] = act ? silu_f(v) : v;
             }
-            *(uint4*)(yc + (long)pix * C) = pack8<T>(f);
+            *(uint4*)(yc + (long)pix * Ct) = pack8<T>(f);
         };
         int pix = pix0 + pl;                       // four loads in flight per thread (see gn_partial_kernel)
         for (; pix + 3 * lanes < pix1; pix += 4 * lanes) {
@@ -252,6 +255,34 @@ static inline int pick_slabs(long N, long HW) {
 
 extern "C" int64_t im360_gn_num_slabs(int64_t N, int64_t H, int64_t W) { return im360::pick_slabs(N, H * W); }
 
+namespace im360 {
+template <typename T>
+static void launch_gn_stats(const void* xa, const void* xb, int64_t C1, int64_t C2, const void* gamma, const void* beta, void* partial,
+                            void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t G, int64_t pad, float eps, hipStream_t s) {
+    const int S = pick_slabs(N, H * W);
+    const int Ct = (int)(C1 + C2);
+    const double count = (double)H * (double)(W + 2 * pad) * (double)(Ct / G);
+    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(S, (unsigned)N), dim3(256), 0, s, (const T*)xa, (float*)partial,
+                       (int)(H * W), (int)W, (int)C1, (int)pad, S, Ct, 0);
+    if (xb)
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(S, (unsigned)N), dim3(256), 0, s, (const T*)xb, (float*)partial,
+                           (int)(H * W), (int)W, (int)C2, (int)pad, S, Ct, (int)C1);
+    hipLaunchKernelGGL((gn_finalize_kernel<T>), dim3((unsigned)(N * G)), dim3(64), 0, s, (const float*)partial, (const T*)gamma,
+                       (const T*)beta, (float*)scale, (float*)shift, (int)N, Ct, (int)G, S, count, eps);
+}
+template <typename T>
+static void launch_gn_apply(const void* xa, const void* xb, int64_t C1, int64_t C2, const void* scale, const void* shift, void* y,
+                            int64_t N, int64_t H, int64_t W, int64_t pad, int act, hipStream_t s) {
+    const int S = pick_slabs(N, H * (W + 2 * pad));
+    const int Ct = (int)(C1 + C2);
+    hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(S, (unsigned)N), dim3(256), 0, s, (const T*)xa, (const float*)scale,
+                       (const float*)shift, (T*)y, (int)H, (int)W, (int)C1, (int)pad, act, S, Ct, 0);
+    if (xb)
+        hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(S, (unsigned)N), dim3(256), 0, s, (const T*)xb, (const float*)scale,
+                           (const float*)shift, (T*)y, (int)H, (int)W, (int)C2, (int)pad, act, S, Ct, (int)C1);
+}
+}  // namespace im360
+
 // x [N,H,W,C]; partial: fp32 workspace of N * S * 2 * C floats with S = im360_gn_num_slabs(N,H,W);
 // scale, shift: fp32 [N, C] outputs.
 extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, void* partial,
@@ -264,27 +295,31 @@ extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const voi
     IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_stats: pad %ld out of range", (long)pad);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0, "groupnorm_stats: misaligned x");
     IM360_CHECK_ARG(N <= 65535, "groupnorm_stats: N=%ld exceeds grid.y", (long)N);
-    const int S = pick_slabs(N, H * W);
-    const double count = (double)H * (double)(W + 2 * pad) * (double)(C / G);
-    hipStream_t s = (hipStream_t)stream;
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_stats: dtype %d unsupported", dtype);
     ProfScope prof(PROF_GN_STATS, stream);
-    const unsigned fb = (unsigned)(N * G);
-    if (dtype == 0) {
-        hipLaunchKernelGGL((gn_partial_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const __bf16*)x,
-                           (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
-        hipLaunchKernelGGL((gn_finalize_kernel<__bf16>), dim3(fb), dim3(64), 0, s, (const float*)partial,
-                           (const __bf16*)gamma, (const __bf16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
-                           (int)G, S, count, eps);
-    } else if (dtype == 1) {
-        hipLaunchKernelGGL((gn_partial_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const _Float16*)x,
-                           (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S);
-        hipLaunchKernelGGL((gn_finalize_kernel<_Float16>), dim3(fb), dim3(64), 0, s, (const float*)partial,
-                           (const _Float16*)gamma, (const _Float16*)beta, (float*)scale, (float*)shift, (int)N, (int)C,
-                           (int)G, S, count, eps);
-    } else {
-        im360_set_error("groupnorm_stats: dtype %d unsupported", dtype);
-        return IM360_ERR_UNSUPPORTED;
-    }
+    if (dtype == 0) launch_gn_stats<__bf16>(x, nullptr, C, 0, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
+    else launch_gn_stats<_Float16>(x, nullptr, C, 0, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// GroupNorm statistics of the channel concatenation [xa | xb] without materialising it (xa [N,H,W,C1], xb [N,H,W,C2];
+// gamma / beta / scale / shift span C1 + C2 channels; partial: N * S * 2 * (C1 + C2) floats).  The decoder's ResnetBlocks
+// normalise torch.cat([x, skip]) (src/models/MVGenModel.py:407-437 -> animatediff/models/resnet.py:221-225).
+extern "C" int im360_groupnorm_stats_cat(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
+                                         void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2,
+                                         int64_t G, int64_t pad, float eps, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(xa && xb && gamma && beta && partial && scale && shift, "groupnorm_stats_cat: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C1 > 0 && C2 > 0 && G > 0, "groupnorm_stats_cat: empty problem");
+    IM360_CHECK_ARG((C1 % 8) == 0 && (C2 % 8) == 0 && ((C1 + C2) % G) == 0, "groupnorm_stats_cat: C1=%ld, C2=%ld must be multiples of 8 and C1 + C2 of G=%ld", (long)C1, (long)C2, (long)G);
+    IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_stats_cat: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0, "groupnorm_stats_cat: misaligned input");
+    IM360_CHECK_ARG(N <= 65535, "groupnorm_stats_cat: N=%ld exceeds grid.y", (long)N);
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_stats_cat: dtype %d unsupported", dtype);
+    ProfScope prof(PROF_GN_STATS, stream);
+    if (dtype == 0) launch_gn_stats<__bf16>(xa, xb, C1, C2, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
+    else launch_gn_stats<_Float16>(xa, xb, C1, C2, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
@@ -299,19 +334,29 @@ extern "C" int im360_groupnorm_apply(const void* x, const void* scale, const voi
     IM360_CHECK_ARG(pad >= 0 && pad <= W, "groupnorm_apply: pad %ld out of range", (long)pad);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0, "groupnorm_apply: misaligned pointer");
     IM360_CHECK_ARG(N <= 65535, "groupnorm_apply: N=%ld exceeds grid.y", (long)N);
-    const int S = pick_slabs(N, H * (W + 2 * pad));
-    hipStream_t s = (hipStream_t)stream;
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_apply: dtype %d unsupported", dtype);
     ProfScope prof(PROF_GN_APPLY, stream);
-    if (dtype == 0)
-        hipLaunchKernelGGL((gn_apply_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const __bf16*)x,
-                           (const float*)scale, (const float*)shift, (__bf16*)y, (int)H, (int)W, (int)C, (int)pad, act, S);
-    else if (dtype == 1)
-        hipLaunchKernelGGL((gn_apply_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, s, (const _Float16*)x,
-                           (const float*)scale, (const float*)shift, (_Float16*)y, (int)H, (int)W, (int)C, (int)pad, act, S);
-    else {
-        im360_set_error("groupnorm_apply: dtype %d unsupported", dtype);
-        return IM360_ERR_UNSUPPORTED;
-    }
+    if (dtype == 0) launch_gn_apply<__bf16>(x, nullptr, C, 0, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
+    else launch_gn_apply<_Float16>(x, nullptr, C, 0, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// y [N, H, W + 2 pad, C1 + C2] = act([xa | xb] * scale + shift): the normalised concatenation is written directly, the
+// concatenation itself never exists (see im360_groupnorm_stats_cat)
+extern "C" int im360_groupnorm_apply_cat(const void* xa, const void* xb, const void* scale, const void* shift, void* y,
+                                         int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t pad, int act,
+                                         int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(xa && xb && scale && shift && y, "groupnorm_apply_cat: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C1 > 0 && C2 > 0 && (C1 % 8) == 0 && (C2 % 8) == 0, "groupnorm_apply_cat: bad shape");
+    IM360_CHECK_ARG(pad >= 0 && pad <= W, "groupnorm_apply_cat: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)y % 16) == 0, "groupnorm_apply_cat: misaligned pointer");
+    IM360_CHECK_ARG(N <= 65535, "groupnorm_apply_cat: N=%ld exceeds grid.y", (long)N);
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_apply_cat: dtype %d unsupported", dtype);
+    ProfScope prof(PROF_GN_APPLY, stream);
+    if (dtype == 0) launch_gn_apply<__bf16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
+    else launch_gn_apply<_Float16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

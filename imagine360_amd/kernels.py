@@ -23,6 +23,12 @@ _SIGNATURES = {
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
     "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
+    "im360_groupnorm_stats_cat": (_INT, [_PTR] * 7 + [_I64] * 7 + [_F32, _INT, _PTR]),
+    "im360_groupnorm_apply_cat": (_INT, [_PTR] * 5 + [_I64] * 6 + [_INT, _INT, _PTR]),
+    "im360_conv1x1_cat_fwd": (_INT, [_PTR] * 6 + [_I64] * 6 + [_INT, _PTR]),
+    "im360_linear_fwd": (_INT, [_PTR] * 6 + [_I64] * 3 + [_INT, _PTR]),
+    "im360_linear_ln_fwd": (_INT, [_PTR] * 5 + [_I64, _F32, _PTR, _I64, _I64, _PTR] + [_I64] * 3 + [_INT, _PTR]),
+    "im360_linear_geglu_ln": (_INT, [_PTR] * 5 + [_I64, _F32, _PTR] + [_I64] * 3 + [_INT, _PTR]),
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
@@ -192,32 +198,50 @@ def temporal_attention(qkv, B, F, P, heads):
 
 # ------------------------------------------------------------------------------------------ group norm
 def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
-    """x [N, H, W, C] channels-last.  Returns fp32 (scale, shift) [N, C] with GN(x) = x*scale + shift;
+    """x [N, H, W, C] channels-last, or a pair (xa [N, H, W, C1], xb [N, H, W, C2]) standing for their channel
+    concatenation (never materialised).  Returns fp32 (scale, shift) [N, C] with GN(x) = x*scale + shift;
     pad > 0 = statistics of the circularly W-padded tensor."""
-    _dev(x, gamma, beta)
-    N, H, W, C = x.shape
-    assert x.is_contiguous() and gamma.dtype == x.dtype and beta.dtype == x.dtype
+    xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+    _dev(xa, xb, gamma, beta)
+    N, H, W, C1 = xa.shape
+    C = C1 + (xb.shape[-1] if xb is not None else 0)
+    assert xa.is_contiguous() and gamma.dtype == xa.dtype and beta.dtype == xa.dtype and gamma.numel() == C
     S = lib().im360_gn_num_slabs(N, H, W)
-    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=x.device)
-    scale = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    shift = torch.empty((N, C), dtype=torch.float32, device=x.device)
-    rc = lib().im360_groupnorm_stats(_p(x), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
-                                     N, H, W, C, groups, pad, float(eps), _dt(x), _stream())
-    _check(rc, "im360_groupnorm_stats")
-    _count("gn_stats", 0.0, x.element_size() * x.numel())
+    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=xa.device)
+    scale = torch.empty((N, C), dtype=torch.float32, device=xa.device)
+    shift = torch.empty((N, C), dtype=torch.float32, device=xa.device)
+    if xb is None:
+        rc = lib().im360_groupnorm_stats(_p(xa), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
+                                         N, H, W, C, groups, pad, float(eps), _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_stats")
+    else:
+        assert xb.is_contiguous() and xb.shape[:3] == xa.shape[:3] and xb.dtype == xa.dtype
+        rc = lib().im360_groupnorm_stats_cat(_p(xa), _p(xb), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
+                                             N, H, W, C1, C - C1, groups, pad, float(eps), _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_stats_cat")
+    _count("gn_stats", 0.0, xa.element_size() * N * H * W * C)
     return scale, shift
 
 
 def group_norm_apply(x, scale, shift, silu, pad=0):
-    """y [N, H, W + 2 pad, C] = act(x * scale + shift), circular along W."""
-    _dev(x, scale, shift)
-    N, H, W, C = x.shape
-    assert x.is_contiguous()
-    y = torch.empty((N, H, W + 2 * pad, C), dtype=x.dtype, device=x.device)
-    rc = lib().im360_groupnorm_apply(_p(x), _p(scale), _p(shift), _p(y), N, H, W, C, pad, int(bool(silu)),
-                                     _dt(x), _stream())
-    _check(rc, "im360_groupnorm_apply")
-    _count("gn_apply", 0.0, x.element_size() * (x.numel() + y.numel()))
+    """y [N, H, W + 2 pad, C] = act(x * scale + shift), circular along W; x as in ``group_norm_stats`` (a pair writes the
+    normalised concatenation directly)."""
+    xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+    _dev(xa, xb, scale, shift)
+    N, H, W, C1 = xa.shape
+    C = C1 + (xb.shape[-1] if xb is not None else 0)
+    assert xa.is_contiguous() and scale.shape == (N, C)
+    y = torch.empty((N, H, W + 2 * pad, C), dtype=xa.dtype, device=xa.device)
+    if xb is None:
+        rc = lib().im360_groupnorm_apply(_p(xa), _p(scale), _p(shift), _p(y), N, H, W, C, pad, int(bool(silu)),
+                                         _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_apply")
+    else:
+        assert xb.is_contiguous() and xb.shape[:3] == xa.shape[:3] and xb.dtype == xa.dtype
+        rc = lib().im360_groupnorm_apply_cat(_p(xa), _p(xb), _p(scale), _p(shift), _p(y), N, H, W, C1, C - C1, pad,
+                                             int(bool(silu)), _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_apply_cat")
+    _count("gn_apply", 0.0, xa.element_size() * (N * H * W * C + y.numel()))
     return y
 
 
@@ -301,6 +325,101 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
         _count("gemm" if linear else "conv", 2.0 * N * hout * wout * Cin * cout * taps,
                es * (x.numel() + cout * taps * Cin + y.numel() * (2 if res is not None else 1)))
     return y
+
+
+def can_conv1x1_cat(c1, c2):
+    return c1 % 64 == 0 and c2 % 64 == 0
+
+
+def conv1x1_cat(xa, xb, w_packed, cout, bias=None, res=None):
+    """1x1 convolution of the channel concatenation [xa | xb] (never materialised): xa [N, H, W, C1], xb [N, H, W, C2],
+    w_packed [CoutPad, 1, C1 + C2] -> [N, H, W, Cout] (+ bias, + res).  C1, C2 multiples of 64."""
+    _dev(xa, xb, w_packed, bias, res)
+    N, H, W, C1 = xa.shape
+    C2 = xb.shape[-1]
+    assert xa.is_contiguous() and xb.is_contiguous() and xb.shape[:3] == xa.shape[:3] and xb.dtype == xa.dtype
+    assert w_packed.shape[1] == 1 and w_packed.shape[2] == C1 + C2, (w_packed.shape, C1, C2)
+    y = torch.empty((N, H, W, cout), dtype=xa.dtype, device=xa.device)
+    assert res is None or (res.shape == y.shape and res.is_contiguous())
+    rc = lib().im360_conv1x1_cat_fwd(_p(xa), _p(xb), _p(w_packed), _p(bias), _p(res), _p(y), N, H, W, C1, C2, cout,
+                                     _dt(xa), _stream())
+    _check(rc, "im360_conv1x1_cat_fwd")
+    _count("conv", 2.0 * N * H * W * (C1 + C2) * cout,
+           xa.element_size() * (xa.numel() + xb.numel() + cout * (C1 + C2) + y.numel() * (2 if res is not None else 1)))
+    return y
+
+
+# ------------------------------------------------------------------------------------------ token-major linears
+ROW_SLICE = 160          # columns per (sum, sum of squares) pair of the row statistics (one wave's share of a 320-column tile)
+
+
+def linear(x, w_packed, n, bias=None, res=None, row_stats=False):
+    """x [..., K] @ W^T + bias (+ res) -> [..., n] on the persistent ring kernel (n % 320 == 0, K % 32 == 0; w_packed from
+    ``pack_conv_weight`` of the [n, K, 1, 1] view).  ``row_stats``: also return fp32 [M, n / 160, 2] = per row and
+    160-column slice (sum, sum of squares) of the stored output -- the LayerNorm statistics a consumer with the
+    normalisation folded in (``linear_ln`` / ``linear_geglu_ln``) needs."""
+    _dev(x, w_packed, bias, res)
+    k = x.shape[-1]
+    m = x.numel() // k
+    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[1] == 1 and n % 320 == 0
+    y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    assert res is None or (res.is_contiguous() and res.numel() == y.numel() and res.dtype == x.dtype)
+    st = torch.empty((m, n // ROW_SLICE, 2), dtype=torch.float32, device=x.device) if row_stats else None
+    rc = lib().im360_linear_fwd(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), _p(st), m, k, n, _dt(x), _stream())
+    _check(rc, "im360_linear_fwd")
+    _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel() * (2 if res is not None else 1))
+           + (0 if st is None else 4 * st.numel()))
+    return (y, st) if row_stats else y
+
+
+def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1):
+    """Linear(LayerNorm(x)) with the normalisation folded into the GEMM: x [..., K] RAW rows, ``stats`` their statistics
+    from the producer (``linear(..., row_stats=True)``), w_packed = pack(gamma (.) W), c1 = row sums of the rounded
+    gamma (.) W, c2 = W beta + bias (fp32 [n]); ``tab`` fp32 [Q, n]: row r also gets tab[(r // tab_div) % Q]."""
+    _dev(x, w_packed, c1, c2, stats, tab)
+    k = x.shape[-1]
+    m = x.numel() // k
+    assert x.is_contiguous() and w_packed.shape[2] == k and n % 320 == 0
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == m and stats.shape[2] == 2
+    for t in (c1, c2):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    assert tab is None or (tab.dtype == torch.float32 and tab.is_contiguous() and tab.shape[-1] == n)
+    y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    rc = lib().im360_linear_ln_fwd(_p(x), _p(w_packed), _p(c1), _p(c2), _p(stats), stats.shape[1], float(eps), _p(tab),
+                                   tab_div, tab.shape[0] if tab is not None else 1, _p(y), m, k, n, _dt(x), _stream())
+    _check(rc, "im360_linear_ln_fwd")
+    _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel()) + 4 * stats.numel())
+    return y
+
+
+def linear_geglu_ln(x, w_packed, c1, c2, stats, eps, inner):
+    """GEGLU(LayerNorm(x)) in one launch: operands as in ``linear_ln`` with the rows of gamma (.) W, c1, c2 in the
+    interleaved order of ``pack_geglu``."""
+    _dev(x, w_packed, c1, c2, stats)
+    k = x.shape[-1]
+    m = x.numel() // k
+    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[0] >= 2 * inner
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == m and stats.shape[2] == 2
+    for t in (c1, c2):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 2 * inner
+    y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
+    rc = lib().im360_linear_geglu_ln(_p(x), _p(w_packed), _p(c1), _p(c2), _p(stats), stats.shape[1], float(eps), _p(y),
+                                     m, k, inner, _dt(x), _stream())
+    _check(rc, "im360_linear_geglu_ln")
+    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()) + 4 * stats.numel())
+    return y
+
+
+def fold_layer_norm(weight, bias, gamma, beta):
+    """Operands of the LayerNorm-folded GEMMs from a Linear (weight [n, K], bias [n] or None) and the LayerNorm in front
+    of it: (gamma (.) W rounded to the weight dtype, c1 = its row sums, c2 = W beta + bias), the vectors in fp32.  c1 is
+    taken from the ROUNDED matrix so that the mean term cancels exactly what the MFMA accumulates."""
+    wg = (weight.detach().float() * gamma.detach().float()[None, :]).to(weight.dtype)
+    c1 = wg.float().sum(dim=1)
+    c2 = weight.detach().float() @ beta.detach().float()
+    if bias is not None:
+        c2 = c2 + bias.detach().float()
+    return wg, c1.contiguous(), c2.contiguous()
 
 
 # ------------------------------------------------------------------------------------------ token-wise
@@ -465,7 +584,8 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
 
 
 # ------------------------------------------------------------------------------------------ tuning knobs
-KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9}
+KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9,
+         "ring_groups": 10}
 
 
 def tuning_set(name, value):

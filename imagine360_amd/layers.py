@@ -76,6 +76,11 @@ class InflatedConv3d(nn.Conv2d):
                               up=up, wrap=wrap, x_off=x_off, wout=wout, temb=temb, imgs_per_temb=imgs_per_temb,
                               res=res, y_off=y_off)
 
+    def forward_cat(self, xa, xb, res=None):
+        """1x1 convolution of the channel concatenation [xa | xb] without materialising it (the decoder's conv_shortcut)."""
+        assert self.kernel_size == (1, 1) and xa.shape[-1] + xb.shape[-1] == self.in_channels
+        return kernels.conv1x1_cat(xa, xb, self.packed_weight(), self.out_channels, bias=self.bias, res=res)
+
     def forward(self, x):
         if x.dim() == 5:
             xc, f = to_cl(x)
@@ -105,41 +110,76 @@ def layer_norm(norm, x, pre=None, post=None, post_div=1):
     return kernels.layer_norm(x.contiguous(), norm.weight, norm.bias, norm.eps, pre=pre, post=post, post_div=post_div)
 
 
+ROUTE_MIN_TOKENS = 65536      # token-major GEMMs with at least this many rows go to the MFMA ring kernel (tests lower it)
+ROUTE_ON_CPU = False          # tests only: take the routed branch without a GPU (kernels monkeypatched by torch stand-ins)
+ROUTE_N_MULT = 320            # output widths the ring kernel's 320-column tiles cover (tests on stand-ins lower it)
+
+
 def _gemm_kernel_pays(m, k, n):
     """Shapes where the implicit-GEMM conv kernel (as a 1x1 conv with its fused bias / residual epilogue) is at least
     as fast as hipBLASLt + a separate residual add: its 256 x 320 tiles need K % 64 == 0, N % 320 == 0 and enough
     work to fill the chip -- measured (tools/bench_kernels.py linear): every level-0 / level-1 token
     count of cfg2 (>= 65 536 tokens) wins or ties, the 40 960-token level-2 shapes lose to hipBLASLt's deep-K kernels."""
-    return k % 64 == 0 and n % 320 == 0 and m >= 65536 and ((m + 255) // 256) * (n // 320) >= 512
+    return k % 64 == 0 and n % ROUTE_N_MULT == 0 and m >= ROUTE_MIN_TOKENS and ((m + 255) // 256) * (n // ROUTE_N_MULT) >= min(512, ROUTE_MIN_TOKENS // 128)
 
 
-def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1"):
+def _routed(x, m, k, n):
+    return (x.is_cuda or ROUTE_ON_CPU) and _gemm_kernel_pays(m, k, n)
+
+
+def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1", row_stats=False):
     """``x @ weight.T + bias (+ res)``.  Large token counts: one launch of the MFMA implicit-GEMM kernel (as a 1x1
     conv over a [M, 1, 1, K] view) with bias and residual in its epilogue -- no separate elementwise pass over the
-    activations; otherwise hipBLASLt (+ an add).  ``cache``: DerivedCache holding the packed weight."""
+    activations; otherwise hipBLASLt (+ an add).  ``cache``: DerivedCache holding the packed weight.
+    ``row_stats``: return (y, stats) where stats are the per-row LayerNorm statistics of y written by the same launch
+    (``kernels.linear``), or None when the GEMM went to hipBLASLt (the consumer then runs the LayerNorm kernel)."""
     n, k = weight.shape
     m = x.numel() // k
-    if not (x.is_cuda and _gemm_kernel_pays(m, k, n)) or (res is not None and res.shape[-1] != n):
+    if not _routed(x, m, k, n) or (res is not None and res.shape[-1] != n):
         y = F.linear(x, weight, bias)
-        return y if res is None else y + res
+        y = y if res is None else y + res
+        return (y, None) if row_stats else y
     wp = cache.get(key, (weight,), lambda: kernels.pack_conv_weight(weight.detach().reshape(n, k, 1, 1)))
+    if row_stats:
+        return kernels.linear(x.contiguous(), wp, n, bias=bias, res=None if res is None else res.contiguous(), row_stats=True)
     r4 = None if res is None else res.contiguous().reshape(m, 1, 1, n)
     y = kernels.conv2d(x.contiguous().reshape(m, 1, 1, k), wp, n, bias=bias, res=r4)
     return y.reshape(*x.shape[:-1], n)
+
+
+def ln_linear(norm, weight, bias, x, stats, cache, key, post=None, post_div=1):
+    """``Linear(LayerNorm(x) [+ post[(row // post_div) % len(post)]])``.  With the rows' statistics from the producing GEMM
+    (``gemm_linear(..., row_stats=True)``) the normalisation is folded into the GEMM (``kernels.linear_ln``): the
+    LayerNorm pass over the activations and its output tensor disappear; without them: LayerNorm kernel + ``gemm_linear``."""
+    n, k = weight.shape
+    m = x.numel() // k
+    if stats is None or not _routed(x, m, k, n):
+        return gemm_linear(weight, bias, layer_norm(norm, x, post=post, post_div=post_div), cache=cache, key=key)
+
+    def build():
+        wg, c1, c2 = kernels.fold_layer_norm(weight, bias, norm.weight, norm.bias)
+        return kernels.pack_conv_weight(wg.reshape(n, k, 1, 1).contiguous()), c1, c2
+
+    wp, c1, c2 = cache.get(key + "_ln", (weight, bias, norm.weight, norm.bias), build)
+    tab = None
+    if post is not None:
+        # the positional rows added AFTER the normalisation go through the projection once: a [Q, n] fp32 table
+        tab = cache.get(key + "_tab", (weight, post), lambda: (post.float() @ weight.detach().float().t()).contiguous())
+    return kernels.linear_ln(x.contiguous(), wp, c1, c2, stats, norm.eps, n, tab=tab, tab_div=post_div)
 
 
 def _module_cache(mod):
     return mod.__dict__.setdefault("_im360_derived", DerivedCache())
 
 
-def linear(lin, x):
+def linear(lin, x, row_stats=False):
     """nn.Linear forward through ``gemm_linear``."""
-    return gemm_linear(lin.weight, lin.bias, x, cache=_module_cache(lin))
+    return gemm_linear(lin.weight, lin.bias, x, cache=_module_cache(lin), row_stats=row_stats)
 
 
-def linear_residual(lin, x, res):
+def linear_residual(lin, x, res, row_stats=False):
     """``lin(x) + res`` through ``gemm_linear``."""
-    return gemm_linear(lin.weight, lin.bias, x, res=res, cache=_module_cache(lin))
+    return gemm_linear(lin.weight, lin.bias, x, res=res, cache=_module_cache(lin), row_stats=row_stats)
 
 
 class GEGLU(nn.Module):
@@ -149,17 +189,30 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
-    def forward(self, x):
+    def forward(self, x, ln=None, stats=None):
+        """``ln`` (nn.LayerNorm): the normalisation in front of the block, applied here -- folded into the GEMM when the
+        rows' statistics ``stats`` came with x (``gemm_linear(..., row_stats=True)``), by the LayerNorm kernel otherwise."""
         two_i, k = self.proj.weight.shape
         m = x.numel() // k
         # large token counts: projection, bias and the gated activation in ONE launch of the MFMA GEMM kernel (the
         # 2I-wide intermediate never goes to HBM); otherwise hipBLASLt + the elementwise kernel
         # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 640 at >= 64k tokens, loses at K = 1280 / 40k)
-        if x.is_cuda and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= 65536:
-            cache = _module_cache(self)
+        fused = (x.is_cuda or ROUTE_ON_CPU) and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= ROUTE_MIN_TOKENS
+        cache = _module_cache(self)
+        bias = None if self.proj.bias is None else self.proj.bias.detach()
+        if fused and ln is not None and stats is not None:
+            def build():
+                wg, c1, c2 = kernels.fold_layer_norm(self.proj.weight, bias, ln.weight, ln.bias)
+                wp, c1p = kernels.pack_geglu(wg, c1)
+                return wp, c1p.contiguous(), kernels.interleave_geglu(wg, c2)[1].contiguous()
+            ps = tuple(t for t in (self.proj.weight, self.proj.bias, ln.weight, ln.bias) if t is not None)
+            wp, c1p, c2p = cache.get("geglu_ln", ps, build)
+            return kernels.linear_geglu_ln(x.contiguous(), wp, c1p, c2p, stats, ln.eps, two_i // 2)
+        if ln is not None:
+            x = layer_norm(ln, x)
+        if fused:
             ps = (self.proj.weight,) if self.proj.bias is None else (self.proj.weight, self.proj.bias)
-            wp, bp = cache.get("geglu", ps, lambda: kernels.pack_geglu(self.proj.weight.detach(),
-                                                                        None if self.proj.bias is None else self.proj.bias.detach()))
+            wp, bp = cache.get("geglu", ps, lambda: kernels.pack_geglu(self.proj.weight.detach(), bias))
             return kernels.linear_geglu(x.contiguous(), wp, bp, two_i // 2)
         return kernels.geglu(self.proj(x))
 
@@ -172,8 +225,9 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x, residual=None):
-        h = self.net[0](x)
+    def forward(self, x, residual=None, ln=None, stats=None):
+        """``ln`` / ``stats``: the LayerNorm in front of the block and (optionally) the statistics of x's rows, see GEGLU."""
+        h = self.net[0](x, ln, stats)
         return self.net[2](h) if residual is None else linear_residual(self.net[2], h, residual)
 
 
@@ -197,8 +251,11 @@ class QKVAttention(nn.Module):
         self._derived = DerivedCache()
         self._use_memory_efficient_attention_xformers = False
 
-    def out_proj(self, x, residual=None):
+    def out_proj(self, x, residual=None, row_stats=False):
+        """Output projection (+ residual in the GEMM epilogue); ``row_stats``: (y, LayerNorm statistics of y's rows or None)."""
         lin = self.to_out[0] if isinstance(self.to_out, nn.ModuleList) else self.to_out
+        if row_stats:
+            return gemm_linear(lin.weight, lin.bias, x, res=residual, cache=_module_cache(lin), row_stats=True)
         return lin(x) if residual is None else linear_residual(lin, x, residual)
 
     def fused_qkv_weight(self):
@@ -209,9 +266,13 @@ class QKVAttention(nn.Module):
         """x [..., C] -> fused [..., 3*inner] (valid when to_q/k/v share their input)."""
         return gemm_linear(self.fused_qkv_weight(), None, x, cache=self._derived, key="qkv_packed")
 
-    def self_attention(self, x, bias=None):
-        """x [B, N, C] -> attention output before the out projection."""
-        qkv = self.qkv(x)
+    def qkv_ln(self, norm, x, stats, post=None, post_div=1):
+        """``qkv(LayerNorm(x) [+ post rows])`` with the normalisation folded into the GEMM when ``stats`` is given."""
+        return ln_linear(norm, self.fused_qkv_weight(), None, x, stats, self._derived, "qkv_packed", post=post, post_div=post_div)
+
+    def self_attention(self, x, bias=None, norm=None, stats=None):
+        """x [B, N, C] -> attention output before the out projection (``norm``: LayerNorm applied to x first)."""
+        qkv = self.qkv(x) if norm is None else self.qkv_ln(norm, x, stats)
         c = self.inner_dim
         return kernels.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads, bias=bias)
 

@@ -111,10 +111,10 @@ class WarpAttn(nn.Module):
         a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed)
         # residual adds ride in the GEMM epilogues where the token count takes the MFMA kernel (same rounding sequence as
         # Linear -> + residual; hipBLASLt + add otherwise)
-        eq = t.attn1.out_proj(a_e, residual=eq)
-        eq = t.ff(layer_norm(t.norm2, eq), residual=eq)
-        pr = t.attn1.out_proj(a_p, residual=pr)
-        pr = t.ff(layer_norm(t.norm2, pr), residual=pr)
+        eq, st = t.attn1.out_proj(a_e, residual=eq, row_stats=True)
+        eq = t.ff(eq, residual=eq, ln=t.norm2, stats=st)              # LayerNorm folded into the GEGLU GEMM where both take the MFMA kernel
+        pr, st = t.attn1.out_proj(a_p, residual=pr, row_stats=True)
+        pr = t.ff(pr, residual=pr, ln=t.norm2, stats=st)
         pers_out = pr.reshape(b, frames, m, ph, pw, c).permute(0, 2, 1, 3, 4, 5).reshape(nf, ph, pw, c)
         return pers_out.contiguous(), eq.reshape(ne_img, eh, ew, c)
 
@@ -294,8 +294,9 @@ class MultiViewBaseModel(nn.Module):
         # ---- up (:395-458)
         for i, (ub, pub) in enumerate(zip(un.up_blocks, pu.up_blocks)):
             for j in range(len(ub.resnets)):
-                x = ub.resnets[j].forward_cl(torch.cat([x, skips.pop()], dim=-1), emb, f)
-                px = pub.resnets[j].forward_cl(torch.cat([px, pskips.pop()], dim=-1), pemb, f, pano)
+                # skip connections: the ResnetBlock reads (x, skip) in place, torch.cat([x, skip]) is never written
+                x = ub.resnets[j].forward_cl((x, skips.pop()), emb, f)
+                px = pub.resnets[j].forward_cl((px, pskips.pop()), pemb, f, pano)
                 if ub.has_cross_attention:           # UpBlock3D's motion modules are skipped (:426-443)
                     x = ub.attentions[j].forward_cl(x, ctx, f)
                     if ub.motion_modules[j] is not None:

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import kernels
 from .layers import (DerivedCache, FeedForward, InflatedConv3d, InflatedGroupNorm, QKVAttention, from_cl, layer_norm,
-                     linear, linear_residual,
+                     linear, linear_residual, ln_linear,
                      to_cl)
 
 
@@ -74,13 +74,23 @@ class ResnetBlock3D(nn.Module):
             self.conv_shortcut = InflatedConv3d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward_cl(self, x, temb, frames, pano=False):
+        """x [N, H, W, C], or a pair (xa, xb) standing for torch.cat([xa, xb], -1) -- the decoder's skip connections
+        (MVGenModel.py:407-437): GroupNorm and the 1x1 shortcut read the two tensors in place, the concatenation is never
+        written."""
         pad = 2 if pano else 0
-        w = x.shape[2]
+        if isinstance(x, (tuple, list)):
+            xa, xb = x
+            if self.conv_shortcut is None or not kernels.can_conv1x1_cat(xa.shape[-1], xb.shape[-1]) or xb.shape[-1] % 8:
+                x = torch.cat([xa, xb], dim=-1)
+        w = (x[0] if isinstance(x, tuple) else x).shape[2]
         h = self.norm1.forward_cl(x, silu=True, pad=pad)
         t = self.time_emb_proj(F.silu(temb)).contiguous() if (temb is not None and self.time_emb_proj is not None) else None
         h = self.conv1.forward_cl(h, temb=t, imgs_per_temb=frames)
         h = self.norm2.forward_cl(h, silu=True)
-        short = x if self.conv_shortcut is None else self.conv_shortcut.forward_cl(x)
+        if isinstance(x, tuple):
+            short = self.conv_shortcut.forward_cat(*x)
+        else:
+            short = x if self.conv_shortcut is None else self.conv_shortcut.forward_cl(x)
         return self.conv2.forward_cl(h, x_off=pad, wout=w, res=short)
 
     def forward(self, input_tensor, temb):
@@ -148,15 +158,20 @@ class IPCrossAttention(QKVAttention):
             ip = ip[:, :, :self.image_cross_attention_dim]
         return self.to_k(text), self.to_v(text), self.to_k_ip(ip), self.to_v_ip(ip)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, frames=None, residual=None):
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, frames=None, residual=None,
+                norm=None, stats=None, row_stats=False):
         """hidden_states [(b f), n, c]; encoder_hidden_states [(b f), 141, d] (reference form) or [b, 141, d]
         with ``frames`` given (one context per video).  ``residual`` is added to the result (fused into the output
-        projection)."""
+        projection).  ``norm``: the LayerNorm in front of the block, applied to hidden_states here (folded into the query
+        projection when the rows' statistics ``stats`` are given); ``row_stats``: return (out, statistics of out's rows)."""
         kv_group = 1
         if frames is not None and encoder_hidden_states.shape[0] * frames == hidden_states.shape[0]:
             kv_group = frames
         kt, vt, ki, vi = self.project_context(encoder_hidden_states)
-        q = linear(self.to_q, hidden_states)
+        if norm is None:
+            q = linear(self.to_q, hidden_states)
+        else:
+            q = ln_linear(norm, self.to_q.weight, self.to_q.bias, hidden_states, stats, self._derived, "to_q_packed")
         ls = self.dim_head ** -0.5 if self._use_memory_efficient_attention_xformers else self.scale
         if self.dim_head == 64:
             # both key / value sets in one launch: Q is read once, nothing is accumulated through HBM
@@ -165,7 +180,7 @@ class IPCrossAttention(QKVAttention):
             out = kernels.attention(q, kt, vt, self.heads, scale=ls, kv_group=kv_group)
             kernels.attention(q, ki, vi, self.heads, scale=ls, kv_group=kv_group, out=out, accumulate=True,
                               out_scale=self.scale)
-        return self.out_proj(out, residual)
+        return self.out_proj(out, residual, row_stats=row_stats)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -186,11 +201,15 @@ class BasicTransformerBlock(nn.Module):
         self.attn1._use_memory_efficient_attention_xformers = flag
         self.attn2._use_memory_efficient_attention_xformers = flag
 
-    def forward(self, hidden_states, encoder_hidden_states=None, frames=None, **_):
+    def forward(self, hidden_states, encoder_hidden_states=None, frames=None, stats=None, **_):
+        """``stats``: LayerNorm statistics of hidden_states' rows when its producer wrote them (layers.gemm_linear).  Each
+        of the three LayerNorms is folded into the GEMM that consumes it whenever the statistics came with the rows; the
+        output projections (+ residual) write the statistics for the next one."""
         y = hidden_states
-        y = self.attn1.out_proj(self.attn1.self_attention(layer_norm(self.norm1, y)), residual=y)
-        y = self.attn2(layer_norm(self.norm2, y), encoder_hidden_states, frames=frames, residual=y)
-        return self.ff(layer_norm(self.norm3, y), residual=y)
+        a = self.attn1.self_attention(y, norm=self.norm1, stats=stats)
+        y, st = self.attn1.out_proj(a, residual=y, row_stats=True)
+        y, st = self.attn2(y, encoder_hidden_states, frames=frames, residual=y, norm=self.norm2, stats=st, row_stats=True)
+        return self.ff(y, residual=y, ln=self.norm3, stats=st)
 
 
 @dataclass
@@ -216,9 +235,10 @@ class Transformer3DModel(nn.Module):
         """x [N, H, W, C]; ctx [N / frames, n_ctx, d] (one context per video)."""
         n, h, w, c = x.shape
         y = self.norm.forward_cl(x).reshape(n, h * w, c)
-        y = linear(self.proj_in, y)
+        y, st = linear(self.proj_in, y, row_stats=True)
         for blk in self.transformer_blocks:
-            y = blk(y, ctx, frames=frames)
+            y = blk(y, ctx, frames=frames, stats=st)
+            st = None
         return linear_residual(self.proj_out, y, x.reshape(n, h * w, c)).reshape(n, h, w, c)
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
@@ -264,13 +284,18 @@ class VersatileAttention(QKVAttention):
             self._pe_key, self._pe_val = key, self.pos_encoder.pe[0, f0:f0 + frames].to(dtype).contiguous()
         return self._pe_val
 
-    def forward(self, tokens, batch, frames, pixels, residual=None):
-        """tokens [batch*frames*pixels, C] token-major, ALREADY normalised and with the frame PE added (the
-        block's fused LayerNorm does both); ``frames`` = frames held by this rank.  ``residual`` is added to the
-        result inside the output projection."""
+    def forward(self, tokens, batch, frames, pixels, residual=None, norm=None, stats=None, row_stats=False):
+        """tokens [batch*frames*pixels, C] token-major.  ``norm`` None: ALREADY normalised and with the frame PE added;
+        else the block's LayerNorm, applied here together with the PE add -- both folded into the QKV GEMM when the rows'
+        statistics ``stats`` are given (the PE rows go through the projection once, as a per-frame table).  ``frames`` =
+        frames held by this rank.  ``residual`` is added to the result inside the output projection; ``row_stats``:
+        return (out, statistics of out's rows)."""
         c = tokens.shape[-1]
         sh = self.frame_shard
-        qkv = self.qkv(tokens)
+        if norm is None:
+            qkv = self.qkv(tokens)
+        else:
+            qkv = self.qkv_ln(norm, tokens, stats, post=self.frame_pe(frames, tokens.dtype), post_div=pixels)
         if sh is None:
             a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads)
         else:
@@ -279,7 +304,7 @@ class VersatileAttention(QKVAttention):
             pp = q.shape[2]
             a = kernels.temporal_attention(q.reshape(-1, 3 * c), batch, sh.total, pp, self.heads)
             a = sh.pixels_to_frames(a.reshape(batch, sh.total, pp, c), pixels).reshape(-1, c)
-        return self.out_proj(a, residual)
+        return self.out_proj(a, residual, row_stats=row_stats)
 
 
 class TemporalTransformerBlock(nn.Module):
@@ -291,11 +316,11 @@ class TemporalTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.ff_norm = nn.LayerNorm(dim)
 
-    def forward(self, y, batch, frames, pixels):
+    def forward(self, y, batch, frames, pixels, stats=None):
+        """``stats``: LayerNorm statistics of y's rows from its producer, or None (see BasicTransformerBlock.forward)."""
         for attn, norm in zip(self.attention_blocks, self.norms):
-            n = layer_norm(norm, y, post=attn.frame_pe(frames, y.dtype), post_div=pixels)      # LN, then + PE[frame]
-            y = attn(n, batch, frames, pixels, residual=y)
-        return self.ff(layer_norm(self.ff_norm, y), residual=y)
+            y, stats = attn(y, batch, frames, pixels, residual=y, norm=norm, stats=stats, row_stats=True)   # LN, + PE[frame], attention
+        return self.ff(y, residual=y, ln=self.ff_norm, stats=stats)
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -313,9 +338,10 @@ class TemporalTransformer3DModel(nn.Module):
     def forward_cl(self, x, frames):
         n, h, w, c = x.shape
         y = self.norm.forward_cl(x).reshape(n * h * w, c)
-        y = linear(self.proj_in, y)
+        y, st = linear(self.proj_in, y, row_stats=True)
         for blk in self.transformer_blocks:
-            y = blk(y, n // frames, frames, h * w)
+            y = blk(y, n // frames, frames, h * w, stats=st)
+            st = None
         return linear_residual(self.proj_out, y, x.reshape(n * h * w, c)).reshape(n, h, w, c)
 
 
@@ -795,7 +821,7 @@ class UNet3DConditionModel(nn.Module):
         x = self.mid_block.forward_cl(x, emb, ctx, f)
         for blk in self.up_blocks:
             for j, res in enumerate(blk.resnets):
-                x = res.forward_cl(torch.cat([x, skips.pop()], dim=-1), emb, f)
+                x = res.forward_cl((x, skips.pop()), emb, f)
                 if blk.has_cross_attention:
                     x = blk.attentions[j].forward_cl(x, ctx, f)
                 if blk.motion_modules[j] is not None:

@@ -82,6 +82,17 @@ int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, v
                           int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
                           int dtype, void* stream);
 
+/* The two GroupNorm passes on the channel concatenation [xa | xb] (xa [N, H, W, C1], xb [N, H, W, C2]) WITHOUT
+ * materialising it: gamma / beta / scale / shift / y span C1 + C2 channels, partial holds N * S * 2 * (C1 + C2) floats.
+ * Replaces: torch.cat([x, skip], dim=1) -> ResnetBlock3D.norm1 in the decoder, src/models/MVGenModel.py:407, 415, 431,
+ *   437 -> animatediff/models/resnet.py:221-225. */
+int im360_groupnorm_stats_cat(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
+                              void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2,
+                              int64_t G, int64_t pad, float eps, int dtype, void* stream);
+int im360_groupnorm_apply_cat(const void* xa, const void* xb, const void* scale, const void* shift, void* y,
+                              int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t pad, int act,
+                              int dtype, void* stream);
+
 /* 3x3 (ntaps = 9) or 1x1 (ntaps = 1) convolution, implicit GEMM on MFMA.  x [N, Hin, Win, Cin],
  * y [N, Hout, Wout, Cout], w_packed from im360_pack_conv_weight.  stride 1|2; up: input is
  * nearest-upsampled x2 on the fly; wrap: circular W addressing; x_off / y_off: column / row offset of the
@@ -95,6 +106,14 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
                    int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
                    int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
                    int64_t imgs_per_temb, int dtype, void* stream);
+
+/* 1x1 convolution of the channel concatenation [xa | xb] without materialising it: the K loop reads channels [0, C1)
+ * from xa and [C1, C1 + C2) from xb (C1, C2 multiples of 64); w_packed [CoutPad][1][C1 + C2]; + bias + res.
+ * Replaces: ResnetBlock3D.conv_shortcut on torch.cat([x, skip]), animatediff/models/resnet.py:248-249 after
+ *   src/models/MVGenModel.py:407, 415, 431, 437. */
+int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void* w_packed, const void* bias, const void* res,
+                          void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t Cout,
+                          int dtype, void* stream);
 
 /* Nearest-x2 upsample followed by conv3x3 (pad 1; wrap: circular along W), computed as four 2 x 2 convolutions of the
  * LOW-resolution input, one per output parity: after the upsample output pixel (2y + py, 2x + px) sees only the 2 x 2 source
@@ -152,6 +171,35 @@ int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, vo
 int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
                        int64_t M, int64_t K, int64_t I, int dtype, void* stream);
 
+/* Token-major Linear y[M, N] = x[M, K] w^T + bias (+ res) on the persistent MFMA kernel (N % 320 == 0, K % 32 == 0,
+ * w_packed = im360_pack_conv_weight of the [N, K, 1, 1] view).  rowstats (optional): fp32 [M][N / 160][2], per row and
+ * 160-column slice (sum, sum of squares) of the STORED 16-bit output -- the LayerNorm statistics of y's rows, taken in
+ * the epilogue that writes them, for a consumer that folds the normalisation into its GEMM (the two functions below).
+ * Replaces: nn.Linear (+ residual add) in front of nn.LayerNorm, animatediff/models/attention.py:264, 461-508;
+ *   motion_module.py:172, 230-258; src/modules/transformer.py:156-165. */
+int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y, void* rowstats,
+                     int64_t M, int64_t K, int64_t N, int dtype, void* stream);
+
+/* Linear(LayerNorm(x)) with the normalisation folded into the GEMM: x [M, K] are the RAW rows, rowstats [M][rs_p][2] their
+ * (sum, sum of squares) slices from im360_linear_fwd, w_packed = pack(gamma (.) W) and
+ *   y[r] = rstd_r * (x[r] w^T - mu_r * c1) + c2 (+ tab[(r / tab_div) % tab_mod])
+ * with fp32 vectors c1[n] = sum_k w'[n][k] (of the rounded 16-bit w'), c2 = W beta + bias; tab (optional, fp32
+ * [tab_mod][N]): rows added AFTER the normalisation pushed through the projection (the motion module's frame positional
+ * encoding).  The LayerNorm pass over the activations and its output tensor do not exist.  Variance = E[x^2] - mu^2 in
+ * fp32 from 16-bit data.  N % 320 == 0, K % 32 == 0.
+ * Replaces: nn.LayerNorm -> to_q / fused to_q,k,v, animatediff/models/attention.py:470-488; motion_module.py:236-250
+ *   (+ pos_encoder :349-350). */
+int im360_linear_ln_fwd(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+                        int64_t rs_p, float eps, const void* tab, int64_t tab_div, int64_t tab_mod, void* y,
+                        int64_t M, int64_t K, int64_t N, int dtype, void* stream);
+
+/* GEGLU(LayerNorm(x)) in one launch: im360_linear_geglu with the normalisation folded in as above; w_packed, c1, c2 in
+ * the interleaved row order of kernels.pack_geglu.
+ * Replaces: nn.LayerNorm -> GEGLU, animatediff/models/attention.py:503-506; motion_module.py:255-257;
+ *   src/modules/transformer.py:164-165. */
+int im360_linear_geglu_ln(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+                          int64_t rs_p, float eps, void* y, int64_t M, int64_t K, int64_t I, int dtype, void* stream);
+
 /* y[r, :] = softmax(x[r, :] * scale), fp32 arithmetic on 16-bit rows (cols and the row strides multiples of 8; in place
  * allowed).  With two launches of im360_conv_fwd as GEMMs it forms the single-head d = 512 attention of the VAE.
  * Replaces: AttentionBlock.forward's softmax(attention_scores.float()), diffusers/models/attention.py:336-364. */
@@ -178,7 +226,8 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * 4 conv/GEMM pipeline: 0 two-stage kernel, 1 persistent ring kernel with interleaved asm LDS-DMA requests, 2 / 3 plain ring
  * (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring kernel for convolutions too; 5 reserved; 6 ablation bits of the
  * ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions; 8 taps-innermost K order of the 3x3 convolutions
- * (default 1); 9 packed-rows LayerNorm at 320 channels (default 1)).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * (default 1); 9 packed-rows LayerNorm at 320 channels (default 1); 10 cout groups of the persistent kernel's tile walk:
+ * 0 = by weight size, 2 / 4 / 8 forced).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
  * change the fp32 summation order, 6 breaks results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);
 

@@ -72,6 +72,48 @@ def test_blocks_against_reference(mv):
             assert rel(p, g["warp_pers_" + tag]) < TOL and rel(e, g["warp_equi_" + tag]) < TOL
 
 
+def test_folded_layernorm_and_skip_pair_paths_against_reference(mv):
+    """The branches the host code takes on the GPU at large token counts -- token-major Linears on the MFMA kernel with the
+    rows' LayerNorm statistics written by the producer, every LayerNorm of the spatial / temporal / cross-view transformer
+    blocks folded into the GEMM that consumes it (gamma-scaled weights, c1 / c2 vectors, the frame-PE table pushed through
+    the QKV projection), fused GEGLU -- forced on CPU with the torch stand-ins, against the REAL reference's fixtures."""
+    g, I, un = gold("ops_w5.npz"), op_inputs(), mv.pano_unet
+    calls = []
+    with E.patched_kernels(), E.routed_gemms():
+        from imagine360_amd import kernels
+        for name in ("linear_ln", "linear_geglu_ln", "linear", "conv1x1_cat"):
+            orig = getattr(kernels, name)
+            setattr(kernels, name, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, name))
+        x, f = to_cl(I["x"])
+        T = un.down_blocks[0].attentions[0]
+        assert rel(from_cl(T.forward_cl(x, I["ctx"], f), f), g["spatial_cpu"]) < TOL
+        assert calls.count("linear_ln") == 2 and calls.count("linear_geglu_ln") == 1 and calls.count("linear") == 3, calls
+        del calls[:]
+        assert rel(un.down_blocks[0].motion_modules[0](I["x"], I["emb"], I["ctx"]), g["motion"]) < TOL
+        assert calls.count("linear_ln") == 2 and calls.count("linear_geglu_ln") == 1, calls
+        x2 = torch.cat([I["x"], I["x"].flip(1), 0.5 * I["x"].roll(3, 1)], 1)
+        xa, _ = to_cl(x2[:, :128])
+        xb, _ = to_cl(x2[:, 128:])
+        del calls[:]
+        out = un.up_blocks[3].resnets[0].forward_cl((xa, xb), I["emb"], f)            # (x, skip) pair, never concatenated
+        assert rel(from_cl(out, f), g["resnet_shortcut"]) < TOL and "conv1x1_cat" in calls
+        cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 64).items()}
+        random.seed(0)
+        del calls[:]
+        p, e = mv.cp_blocks_encoder[0](I["px"], I["ex"], cams)
+        assert rel(p, g["warp_pers_normal"]) < TOL and rel(e, g["warp_equi_normal"]) < TOL and calls.count("linear_geglu_ln") == 2
+    inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=0, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    mv.unet.disable_xformers_memory_efficient_attention()
+    mv.pano_unet.disable_xformers_memory_efficient_attention()
+    with E.patched_kernels(), E.routed_gemms():
+        torch.manual_seed(7)
+        random.seed(7)
+        pers, pano = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **inp)
+    gm = gold("mv_forward_w5.npz")
+    assert rel(pano, gm["pano"]) < TOL and rel(pers[:, [0, 7, 13, 19]], gm["pers_views"]) < TOL
+
+
 def test_cross_view_geometry_against_reference():
     g = gold("masks.npz")
     for ph, eh in ((4, 8), (8, 16)):

@@ -21,6 +21,16 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+def blockrel(a, b, rows=256):
+    """max over blocks of `rows` consecutive rows (last dim = one row) of the block's relative L2 error: a wrong tile edge,
+    a dropped row or one bad 32-row MFMA block cannot hide in a whole-tensor norm."""
+    a, b = a.double().cpu().reshape(-1, a.shape[-1]), b.double().cpu().reshape(-1, b.shape[-1])
+    n = (a.shape[0] + rows - 1) // rows * rows
+    pad = lambda t: torch.cat([t, torch.zeros(n - t.shape[0], t.shape[1], dtype=t.dtype)]).reshape(n // rows, -1)
+    num, den = pad(a - b).norm(dim=1), pad(b).norm(dim=1)
+    return float((num / den.clamp_min(1e-30 + 1e-3 * float(den.max()))).max())
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -556,3 +566,151 @@ def test_geglu(dt):
     h = q16(rnd(333, 2 * 1280, seed=45) * 2, dt)
     a, g = h.chunk(2, dim=-1)
     assert rel(K.geglu(h.to(dt).cuda()), a * F.gelu(g)) < TOL[dt]
+
+
+# ------------------------------------------------------------------ round 3: skip pairs, row statistics, folded LayerNorm
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C1,C2,pad", [(3, 8, 16, 64, 64, 0), (2, 16, 32, 640, 320, 2), (4, 8, 8, 1280, 640, 0), (2, 6, 10, 320, 320, 2)])
+def test_group_norm_of_a_skip_pair_equals_the_concatenation(dt, N, H, W, C1, C2, pad):
+    """GroupNorm statistics / apply reading (x, skip) in place == the same kernels on torch.cat([x, skip]) bit for bit
+    (per-channel partial sums are independent of the other tensor), incl. group boundaries that straddle the two tensors
+    (960 channels: 30 per group) and the pad-aware statistics."""
+    xa, xb = q16(rnd(N, H, W, C1, seed=70) + 0.3, dt).to(dt).cuda(), q16(rnd(N, H, W, C2, seed=71) * 1.5, dt).to(dt).cuda()
+    C = C1 + C2
+    gamma, beta = (1 + 0.1 * rnd(C, seed=72)).to(dt).cuda(), (0.1 * rnd(C, seed=73)).to(dt).cuda()
+    cat = torch.cat([xa, xb], dim=-1).contiguous()
+    s1, h1 = K.group_norm_stats((xa, xb), gamma, beta, 32, 1e-5, pad=pad)
+    s2, h2 = K.group_norm_stats(cat, gamma, beta, 32, 1e-5, pad=pad)
+    assert torch.equal(s1, s2) and torch.equal(h1, h2)
+    y1, y2 = K.group_norm_apply((xa, xb), s1, h1, True, pad=pad), K.group_norm_apply(cat, s2, h2, True, pad=pad)
+    assert y1.shape == (N, H, W + 2 * pad, C) and torch.equal(y1, y2)
+    ref = F.silu(F.group_norm(OG.pad_pano(cat.float().cpu().permute(0, 3, 1, 2), pad), 32, gamma.float().cpu(), beta.float().cpu(), 1e-5)).permute(0, 2, 3, 1)
+    assert rel(y1, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C1,C2,Cout", [(640, 16, 16, 640, 320, 320),      # 256 x 320 tiles, 64-channel steps
+                                               (3, 8, 12, 128, 64, 128),          # 128 x 128 tiles
+                                               (2, 9, 7, 64, 192, 200),           # odd Cout, ragged pixel tile
+                                               (5, 4, 4, 1280, 1280, 1280)])
+def test_conv1x1_of_a_skip_pair_equals_the_concatenation(dt, N, H, W, C1, C2, Cout):
+    """conv_shortcut on (x, skip) read in place: same K order as the 1x1 conv of the materialised concatenation, so the
+    results agree bit for bit; + residual + bias; against fp32 too."""
+    xa, xb = q16(rnd(N, H, W, C1, seed=74), dt).to(dt).cuda(), q16(rnd(N, H, W, C2, seed=75), dt).to(dt).cuda()
+    w = q16(rnd(Cout, C1 + C2, 1, 1, seed=76, scale=(C1 + C2) ** -0.5), dt).to(dt).cuda()
+    b, r = q16(rnd(Cout, seed=77, scale=0.1), dt).to(dt).cuda(), q16(rnd(N, H, W, Cout, seed=78), dt).to(dt).cuda()
+    wp = K.pack_conv_weight(w)
+    cat = torch.cat([xa, xb], dim=-1).contiguous()
+    y1 = K.conv1x1_cat(xa, xb, wp, Cout, bias=b, res=r)
+    y2 = K.conv2d(cat, wp, Cout, bias=b, res=r)
+    assert torch.equal(y1, y2)
+    ref = F.linear(cat.float().cpu(), w.float().cpu().reshape(Cout, -1), b.float().cpu()) + r.float().cpu()
+    assert rel(y1, ref) < TOL[dt] and blockrel(y1, ref) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,Kd,N", [(70000 + 77, 320, 320), (66000, 640, 640), (300, 320, 960), (65536, 1280, 320)])
+def test_linear_row_statistics(dt, M, Kd, N):
+    """im360_linear_fwd: same output as the conv-kernel route of the Linear (bit for bit), and the (sum, sum of squares)
+    slices it writes in the epilogue == sums over the STORED output, ragged last token tile included."""
+    x = q16(rnd(M, Kd, seed=80), dt).to(dt).cuda()
+    w = q16(rnd(N, Kd, seed=81, scale=Kd ** -0.5), dt).to(dt).cuda()
+    b, r = q16(rnd(N, seed=82, scale=0.2), dt).to(dt).cuda(), q16(rnd(M, N, seed=83) + 0.7, dt).to(dt).cuda()
+    wp = K.pack_conv_weight(w.reshape(N, Kd, 1, 1))
+    y, st = K.linear(x, wp, N, bias=b, res=r, row_stats=True)
+    y0 = K.conv2d(x.reshape(M, 1, 1, Kd), wp, N, bias=b, res=r.reshape(M, 1, 1, N)).reshape(M, N)
+    assert torch.equal(y, y0) and torch.equal(K.linear(x, wp, N, bias=b, res=r), y0)
+    t = y.double().reshape(M, N // 160, 160)
+    ref = torch.stack([t.sum(-1), (t * t).sum(-1)], dim=-1)
+    assert st.shape == (M, N // 160, 2) and (st.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    fref = F.linear(x.float(), w.float(), b.float()) + r.float()
+    assert rel(y, fref) < TOL[dt] and blockrel(y, fref) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,C,N,frames,pixels,offset", [(70000 + 13, 320, 960, 0, 0, 0.0), (66000, 640, 1920, 0, 0, 2.0),
+                                                         (2 * 16 * 2304, 320, 960, 16, 2304, 0.5), (1000, 320, 320, 8, 125, 4.0)])
+def test_linear_with_folded_layer_norm(dt, M, C, N, frames, pixels, offset):
+    """Linear(LayerNorm(y) [+ PE[frame]]) as ONE GEMM on the raw rows (im360_linear_ln_fwd) with the statistics the
+    producer wrote (im360_linear_fwd), against fp32 torch and against the LayerNorm-kernel + GEMM route; row means up to
+    4 sigma (variance from E[x^2] - mu^2)."""
+    from imagine360_amd import layers
+    g = torch.Generator().manual_seed(90)
+    prod = torch.nn.Linear(C, C).to(dt).cuda()
+    x0 = (torch.randn(M, C, generator=g)).to(dt).cuda()
+    res = (torch.randn(M, C, generator=g) + offset).to(dt).cuda()
+    y, st = layers.gemm_linear(prod.weight, prod.bias, x0, res=res, cache=layers.DerivedCache(), row_stats=True)
+    saved = layers.ROUTE_MIN_TOKENS
+    layers.ROUTE_MIN_TOKENS = 0
+    try:
+        if st is None:        # small M: below the routing threshold, force the MFMA route
+            y, st = layers.gemm_linear(prod.weight, prod.bias, x0, res=res, cache=layers.DerivedCache(), row_stats=True)
+        assert st is not None and st.shape == (M, C // 160, 2)
+        norm = torch.nn.LayerNorm(C).to(dt).cuda()
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+            norm.bias.copy_(0.2 * torch.randn(C, generator=g))
+        w = (torch.randn(N, C, generator=g) * C ** -0.5).to(dt).cuda()
+        bias = (torch.randn(N, generator=g) * 0.1).to(dt).cuda()
+        post = (torch.randn(frames, C, generator=g) * 0.5).to(dt).cuda() if frames else None
+        out = layers.ln_linear(norm, w, bias, y, st, layers.DerivedCache(), "t", post=post, post_div=max(pixels, 1))
+        unf = layers.ln_linear(norm, w, bias, y, None, layers.DerivedCache(), "t", post=post, post_div=max(pixels, 1))
+    finally:
+        layers.ROUTE_MIN_TOKENS = saved
+    n32 = F.layer_norm(y.float(), (C,), norm.weight.float(), norm.bias.float(), norm.eps)
+    if frames:
+        n32 = n32 + post.float()[(torch.arange(M, device="cuda") // pixels) % frames]
+    ref = F.linear(n32, w.float(), bias.float())
+    e_f, e_u = rel(out, ref), rel(unf, ref)
+    assert out.shape == (M, N) and e_f < TOL[dt] and blockrel(out, ref) < 2 * TOL[dt], (e_f, e_u)
+    assert e_f < 1.5 * e_u + 1e-4, (e_f, e_u)            # no worse than normalising first (one 16-bit rounding fewer)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,C", [(70000 + 5, 320), (66000, 640)])
+def test_geglu_with_folded_layer_norm(dt, M, C):
+    """GEGLU(LayerNorm(y)) in one launch (im360_linear_geglu_ln) against fp32 torch and the LayerNorm + fused-GEGLU route."""
+    from imagine360_amd import layers
+    g = torch.Generator().manual_seed(91)
+    prod = torch.nn.Linear(C, C).to(dt).cuda()
+    norm = torch.nn.LayerNorm(C).to(dt).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        norm.bias.copy_(0.2 * torch.randn(C, generator=g))
+    mod = layers.GEGLU(C, 4 * C).to(dt).cuda()
+    saved = layers.ROUTE_MIN_TOKENS
+    layers.ROUTE_MIN_TOKENS = 0             # (the token counts here are below the routing threshold of the model code)
+    try:
+        y, st = layers.gemm_linear(prod.weight, prod.bias, torch.randn(M, C, generator=g).to(dt).cuda(),
+                                   res=(torch.randn(M, C, generator=g) + 1.0).to(dt).cuda(), cache=layers.DerivedCache(), row_stats=True)
+        assert st is not None
+        out = mod(y, norm, st)
+        unf = mod(y, norm, None)
+    finally:
+        layers.ROUTE_MIN_TOKENS = saved
+    h = F.linear(F.layer_norm(y.float(), (C,), norm.weight.float(), norm.bias.float(), norm.eps), mod.proj.weight.float(), mod.proj.bias.float())
+    ref = h[:, :4 * C] * F.gelu(h[:, 4 * C:])
+    e_f, e_u = rel(out, ref), rel(unf, ref)
+    assert out.shape == (M, 4 * C) and e_f < TOL[dt] and blockrel(out, ref) < 2 * TOL[dt], (e_f, e_u)
+    assert e_f < 1.5 * e_u + 1e-4, (e_f, e_u)
+
+
+def test_ring_kernel_cout_groups_are_bit_identical():
+    """The tile walk of the persistent GEMM kernel with the cout tiles split over XCD groups (the level-1 GEGLU projection,
+    6.5 MB of weights: two groups by default) produces the same bits as the plain walk; forced 2 / 4 groups on a Linear too."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(92)
+    x = torch.randn(66000, 640, generator=g).to(dt).cuda()
+    w = (torch.randn(5120, 640, generator=g) * 640 ** -0.5).to(dt).cuda()
+    b = (torch.randn(5120, generator=g) * 0.1).to(dt).cuda()
+    wp, bp = K.pack_geglu(w, b)
+    lw = K.pack_conv_weight((torch.randn(1280, 640, generator=g) * 640 ** -0.5).to(dt).cuda().reshape(1280, 640, 1, 1))
+    try:
+        K.tuning_set("ring_groups", 1)
+        ref, lref = K.linear_geglu(x, wp, bp, 2560), K.linear(x, lw, 1280)
+        for ng in (0, 2, 4):
+            K.tuning_set("ring_groups", ng)
+            assert torch.equal(K.linear_geglu(x, wp, bp, 2560), ref), ng
+            assert torch.equal(K.linear(x, lw, 1280), lref), ng
+    finally:
+        K.tuning_set("ring_groups", 0)
