@@ -86,10 +86,21 @@ def mv_inputs(frames=16, pano_hw=(32, 64), pers_hw=(16, 16), views=20, seed=0, s
         reference_images_clip_feat_pano=feat_pano, reference_images_clip_feat_pers=feat_pers,
         relative_position_tensor=rel, pitchs_tensor=pitch)
     for k, v in out.items():
-        if torch.is_floating_point(v):
+        if torch.is_floating_point(v) and k not in FP32_INPUTS:
             v = v.to(dtype)
         out[k] = v.to(device)
     return out
+
+
+# Scalar conditioning (frame rate, crop rectangle, camera pitch in degrees): the pipeline hands these to the model as
+# float32 whatever the latent dtype is (pipeline.py, like pipeline_animation_inference_dual.py:608-613) -- a pitch rounded to
+# bf16 is a different camera (17.3 -> 17.25 degrees shifts its sinusoidal embedding by 5 %), not a rounding of the same one.
+FP32_INPUTS = ("fps_tensor_pano", "fps_tensor_pers", "relative_position_tensor", "pitchs_tensor")
+
+
+def cast_mv_inputs(inp, device, dtype):
+    """``mv_inputs`` tensors -> device, the activations in ``dtype``, the scalar conditioning left in float32."""
+    return {k: (v.to(device, dtype) if torch.is_floating_point(v) and k not in FP32_INPUTS else v.to(device)) for k, v in inp.items()}
 
 
 def video_batch(frames=16, pano_hw=(256, 512), seed=0, fps=8, anchor_hw=(64, 64)):

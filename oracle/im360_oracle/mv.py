@@ -44,10 +44,10 @@ def warp_attn(sd, p, pers_x, equi_x, cameras, opposite=None, masks=None):
         ctx = U.layer_norm(sd, t + "norm1.", ctx_wpe)
         a = U.sdpa(U.linear(sd, t + "attn1.to_q.", q_in), U.linear(sd, t + "attn1.to_k.", ctx),
                    U.linear(sd, t + "attn1.to_v.", ctx), heads, bias=bias)
-        x = U.linear(sd, t + "attn1.to_out.", a) + x
+        x = U._st(U.linear(sd, t + "attn1.to_out.", a) + x)        # (U._st: identity unless a test emulates 16-bit storage)
         h = U.linear(sd, t + "ff.net.0.proj.", U.layer_norm(sd, t + "norm2.", x))
         a_, gate = h.chunk(2, dim=-1)
-        return U.linear(sd, t + "ff.net.2.", a_ * F.gelu(gate)) + x
+        return U._st(U.linear(sd, t + "ff.net.2.", a_ * F.gelu(gate)) + x)
 
     eq_out = block(eq, eq_pe, pr + pr_pe, bias_e2p)
     pr_out = block(pr, pr_pe, eq + eq_pe, bias_p2e)

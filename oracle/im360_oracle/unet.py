@@ -9,21 +9,50 @@ import torch
 import torch.nn.functional as F
 
 
+# ----------------------------------------------------------------------------- storage emulation (calibration only)
+# None: plain fp32 (the oracle proper, what every golden fixture was generated with).  A 16-bit dtype: the OUTPUT of every
+# primitive below (Linear, LayerNorm, GroupNorm, conv, attention) is rounded to that dtype and back while the arithmetic
+# stays fp32 -- a model of "16-bit storage, fp32 accumulation" that contains no kernel at all.  Tests use it to calibrate
+# their tolerances: the error of this emulation against the fp32 oracle is what storage rounding ALONE costs on a given
+# network, so a product error far above it points at a kernel, not at the number format.
+STORE_DTYPE = None
+
+
+def _st(x):
+    return x if STORE_DTYPE is None else x.to(STORE_DTYPE).float()
+
+
+class storage:
+    """``with storage(torch.bfloat16): ...`` -- see STORE_DTYPE."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global STORE_DTYPE
+        self.saved, STORE_DTYPE = STORE_DTYPE, self.dtype
+
+    def __exit__(self, *a):
+        global STORE_DTYPE
+        STORE_DTYPE = self.saved
+        return False
+
+
 # ----------------------------------------------------------------------------- primitives
 def linear(sd, p, x):
-    return F.linear(x, sd[p + "weight"], sd.get(p + "bias"))
+    return _st(F.linear(x, sd[p + "weight"], sd.get(p + "bias")))
 
 
 def layer_norm(sd, p, x, eps=1e-5):
     w = sd[p + "weight"]
-    return F.layer_norm(x, (w.shape[0],), w, sd[p + "bias"], eps)
+    return _st(F.layer_norm(x, (w.shape[0],), w, sd[p + "bias"], eps))
 
 
 def conv2d_frames(sd, p, x, stride=1, padding=1):
     """InflatedConv3d = nn.Conv2d on (b f) c h w  (animatediff/models/resnet.py:19-27)."""
     b, c, f, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
-    y = F.conv2d(y, sd[p + "weight"], sd.get(p + "bias"), stride=stride, padding=padding)
+    y = _st(F.conv2d(y, sd[p + "weight"], sd.get(p + "bias"), stride=stride, padding=padding))
     return y.reshape(b, f, *y.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
@@ -31,7 +60,7 @@ def group_norm_frames(sd, p, x, groups, eps):
     """InflatedGroupNorm: per-(b f) statistics (animatediff/models/resnet.py:9-17)."""
     b, c, f, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
-    y = F.group_norm(y, groups, sd[p + "weight"], sd[p + "bias"], eps)
+    y = _st(F.group_norm(y, groups, sd[p + "weight"], sd[p + "bias"], eps))
     return y.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
 
 
@@ -47,7 +76,7 @@ def sdpa(q, k, v, heads, bias=None, scale=None):
     if bias is not None:
         s = s + bias
     o = torch.matmul(s.softmax(-1), vh)
-    return o.transpose(1, 2).reshape(B, Nq, C)
+    return _st(o.transpose(1, 2).reshape(B, Nq, C))
 
 
 def geglu_ff(sd, p, x):
@@ -85,7 +114,7 @@ def resnet_block(sd, p, x, temb, groups=32, eps=1e-5):
     h = conv2d_frames(sd, p + "conv2.", h)
     if (p + "conv_shortcut.weight") in sd:
         x = conv2d_frames(sd, p + "conv_shortcut.", x, padding=0)
-    return x + h
+    return _st(x + h)
 
 
 def downsample(sd, p, x):
@@ -121,7 +150,7 @@ def spatial_transformer(sd, p, x, ctx, heads, num_tokens, groups=32, xformers=Fa
     n = layer_norm(sd, tb + "norm1.", y)
     a = sdpa(linear(sd, tb + "attn1.to_q.", n), linear(sd, tb + "attn1.to_k.", n),
              linear(sd, tb + "attn1.to_v.", n), heads)
-    y = linear(sd, tb + "attn1.to_out.0.", a) + y
+    y = _st(linear(sd, tb + "attn1.to_out.0.", a) + y)          # (the 16-bit residual stream is re-rounded by every add)
     # text + IP cross attention sharing the query, scale 1.0
     n = layer_norm(sd, tb + "norm2.", y)
     end = ctx.shape[1] - num_tokens
@@ -131,12 +160,12 @@ def spatial_transformer(sd, p, x, ctx, heads, num_tokens, groups=32, xformers=Fa
     a = sdpa(q, linear(sd, tb + "attn2.to_k.", text), linear(sd, tb + "attn2.to_v.", text), heads, scale=cs)
     a = a + 1.0 * sdpa(q, linear(sd, tb + "attn2.to_k_ip.", ip), linear(sd, tb + "attn2.to_v_ip.", ip), heads,
                        scale=cs)
-    y = linear(sd, tb + "attn2.to_out.0.", a) + y
+    y = _st(linear(sd, tb + "attn2.to_out.0.", a) + y)
     # feed forward
-    y = geglu_ff(sd, tb + "ff.", layer_norm(sd, tb + "norm3.", y)) + y
+    y = _st(geglu_ff(sd, tb + "ff.", layer_norm(sd, tb + "norm3.", y)) + y)
     y = linear(sd, p + "proj_out.", y)
     y = y.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
-    return y + res
+    return _st(y + res)
 
 
 # ----------------------------------------------------------------------------- motion module
@@ -169,11 +198,11 @@ def motion_module(sd, p, x, heads=8, groups=32):
         a = sdpa(linear(sd, ab + "to_q.", t), linear(sd, ab + "to_k.", t), linear(sd, ab + "to_v.", t), heads)
         a = linear(sd, ab + "to_out.0.", a)
         a = a.reshape(b, h * w, f, c).permute(0, 2, 1, 3).reshape(b * f, h * w, c)
-        y = a + y
-    y = geglu_ff(sd, tb + "ff.", layer_norm(sd, tb + "ff_norm.", y)) + y
+        y = _st(a + y)
+    y = _st(geglu_ff(sd, tb + "ff.", layer_norm(sd, tb + "ff_norm.", y)) + y)
     y = linear(sd, p + "proj_out.", y)
     y = y.reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3)
-    return y + res
+    return _st(y + res)
 
 
 # ----------------------------------------------------------------------------- IP adapter
