@@ -203,6 +203,9 @@ def test_graph_replayed_step_equals_eager_step():
 
 
 # ------------------------------------------------------------------ full-width blocks, cfg4 / cfg5 sized kernels
+_BLOCK_ORACLE = {}
+
+
 @pytest.mark.parametrize("routed", [False, True])
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2e-2), (torch.float16, 5e-3)])
 @pytest.mark.parametrize("level,c,heads,hw", [(0, 320, 5, (16, 16)), (1, 640, 10, (8, 16)), (2, 1280, 20, (8, 8))])
@@ -217,7 +220,7 @@ def test_full_width_block_vs_oracle(dt, tol, level, c, heads, hw, routed):
     consuming GEMM and the fused GEGLU run here at full width.
 
     Calibration: the same blocks through the oracle with every primitive's output ROUNDED to the 16-bit dtype (fp32
-    arithmetic, no kernel involved) give the error that storage alone costs; the product must stay within 1.5x of it."""
+    arithmetic, no kernel involved) give the error that storage alone costs; the product must stay within 1.25x of it."""
     from imagine360_amd import layers
     from imagine360_amd.layers import from_cl, to_cl
     from imagine360_amd.mv_model import MultiViewBaseModel
@@ -247,38 +250,39 @@ def test_full_width_block_vs_oracle(dt, tol, level, c, heads, hw, routed):
     ctx = _q(torch.randn(b, 141, 1024, generator=g), dt)
     xc, _ = to_cl(x.to(dev, dt))
     errs, cal = {}, {}
+    key = (level, dt)
+    if key not in _BLOCK_ORACLE:            # the oracle (fp32 and storage-rounded) once per (level, dtype), shared by both routings
+        from im360_oracle import geometry as OG
+        o = OU.resnet_block(sd, pre + "resnets.0.", x, emb)
+        o2 = OU.spatial_transformer(sd, pre + "attentions.0.", o, ctx, heads, 64, xformers=True)
+        o3 = OU.motion_module(sd, pre + "motion_modules.0.", o2)
+        op = OG.unpad_pano(OU.resnet_block(sd, pre + "resnets.0.", OG.pad_pano(x, 2), emb), 2)
+        with OU.storage(dt):                     # what 16-bit storage alone costs on these blocks
+            c1 = OU.resnet_block(sd, pre + "resnets.0.", x, emb)
+            c2 = OU.spatial_transformer(sd, pre + "attentions.0.", c1, ctx, heads, 64, xformers=True)
+            c3 = OU.motion_module(sd, pre + "motion_modules.0.", c2)
+        _BLOCK_ORACLE[key] = (o, o2, o3, op, {"resnet": rel(c1, o), "transformer": rel(c2, o2), "motion": rel(c3, o3)})
+    o, o2, o3, op, cal = _BLOCK_ORACLE[key]
     saved = layers.ROUTE_MIN_TOKENS
     if routed:
         layers.ROUTE_MIN_TOKENS = 0
     try:
         for pano in (False, True):
             y = res.forward_cl(xc, emb.to(dev, dt), f, pano)
-            if pano:
-                from im360_oracle import geometry as OG
-                o = OG.unpad_pano(OU.resnet_block(sd, pre + "resnets.0.", OG.pad_pano(x, 2), emb), 2)
-            else:
-                o = OU.resnet_block(sd, pre + "resnets.0.", x, emb)
-            errs["resnet_pano" if pano else "resnet"] = rel(from_cl(y, f), o)
+            errs["resnet_pano" if pano else "resnet"] = rel(from_cl(y, f), op if pano else o)
             if pano:
                 continue
             y2 = tr.forward_cl(y, ctx.to(dev, dt), f)
-            o2 = OU.spatial_transformer(sd, pre + "attentions.0.", o, ctx, heads, 64, xformers=True)
             errs["transformer"] = rel(from_cl(y2, f), o2)
             y3 = mm.forward_cl(y2, f)
-            o3 = OU.motion_module(sd, pre + "motion_modules.0.", o2)
             errs["motion"] = rel(from_cl(y3, f), o3)
-            with OU.storage(dt):                     # what 16-bit storage alone costs on these blocks
-                c1 = OU.resnet_block(sd, pre + "resnets.0.", x, emb)
-                c2 = OU.spatial_transformer(sd, pre + "attentions.0.", c1, ctx, heads, 64, xformers=True)
-                c3 = OU.motion_module(sd, pre + "motion_modules.0.", c2)
-            cal = {"resnet": rel(c1, o), "transformer": rel(c2, o2), "motion": rel(c3, o3)}
     finally:
         layers.ROUTE_MIN_TOKENS = saved
     _record(f"full_width_block_L{level}_{str(dt).split('.')[-1]}" + ("_routed" if routed else ""), **errs,
             **{"storage_only_" + k: v for k, v in cal.items()})
     assert max(errs.values()) < tol, errs
     for k, v in cal.items():
-        assert errs[k] <= 1.5 * v + 1e-4, (k, errs, cal)
+        assert errs[k] <= 1.25 * v + 1e-4, (k, errs, cal)       # (round 2 measured 1.03 - 1.04x on every block)
 
 
 def test_full_width_cfg1_step_and_vae_frame_vs_oracle():

@@ -241,6 +241,55 @@ def bench_geglu_fused(iters):
         print(f"geglu_fused {name:8s} M={M:6d} C={C:4d}: torch+geglu {t1 * 1e3:7.3f} ms | fused {t2 * 1e3:7.3f} ms {fl / t2 / 1e12:6.0f} TF/s")
 
 
+def bench_lnfold(iters):
+    """Round 3: LayerNorm folded into the consuming GEMM (row statistics from the producer's epilogue) vs the LayerNorm
+    kernel + GEMM; the producer with and without the statistics; the skip pair (x, skip) read in place vs torch.cat; the
+    cout-grouped tile walk on the level-1 GEGLU projection."""
+    import torch.nn as nn
+    from imagine360_amd import layers
+    for name, M, C in [("pers L0", 655360, 320), ("pano L0", 262144, 320), ("pers L1", 163840, 640), ("pano L1", 65536, 640)]:
+        prod, norm = nn.Linear(C, C).to(DEV, DT), nn.LayerNorm(C).to(DEV, DT)
+        x, res = rn(M, C), rn(M, C)
+        cache = layers.DerivedCache()
+        t_p0 = timeit(lambda: layers.gemm_linear(prod.weight, prod.bias, x, res=res, cache=cache), iters)
+        t_p1 = timeit(lambda: layers.gemm_linear(prod.weight, prod.bias, x, res=res, cache=cache, row_stats=True), iters)
+        y, st = layers.gemm_linear(prod.weight, prod.bias, x, res=res, cache=cache, row_stats=True)
+        wq = rn(3 * C, C) * C ** -0.5
+        c2 = layers.DerivedCache()
+        t_ln = timeit(lambda: layers.layer_norm(norm, y), iters)
+        t_u = timeit(lambda: layers.ln_linear(norm, wq, None, y, None, c2, "q"), iters)
+        t_f = timeit(lambda: layers.ln_linear(norm, wq, None, y, st, c2, "q"), iters)
+        ff = layers.GEGLU(C, 4 * C).to(DEV, DT)
+        t_gu = timeit(lambda: ff(y, norm, None), iters)
+        t_gf = timeit(lambda: ff(y, norm, st), iters)
+        print(f"lnfold {name:8s} M={M:6d} C={C:4d}: out-proj+res {t_p0 * 1e3:6.3f} ms, with row stats {t_p1 * 1e3:6.3f} | LN {t_ln * 1e3:6.3f} | "
+              f"LN+qkv {t_u * 1e3:6.3f} -> folded {t_f * 1e3:6.3f} | LN+GEGLU {t_gu * 1e3:6.3f} -> folded {t_gf * 1e3:6.3f}")
+    for name, N, H, W, C1, C2, Cout in [("pers up L0", 640, 32, 32, 320, 320, 320), ("pers up L0", 640, 32, 32, 640, 320, 320),
+                                         ("pers up L1", 640, 16, 16, 1280, 640, 640), ("pano up L0", 32, 64, 128, 320, 320, 320)]:
+        xa, xb = rn(N, H, W, C1), rn(N, H, W, C2)
+        g, b = rn(C1 + C2), rn(C1 + C2)
+        wp = K.pack_conv_weight(rn(Cout, C1 + C2, 1, 1) * (C1 + C2) ** -0.5)
+
+        def old():
+            c = torch.cat([xa, xb], dim=-1)
+            h = K.group_norm(c, g, b, 32, 1e-5, silu=True)
+            return h, K.conv2d(c, wp, Cout)
+
+        def new():
+            h = K.group_norm((xa, xb), g, b, 32, 1e-5, silu=True)
+            return h, K.conv1x1_cat(xa, xb, wp, Cout)
+
+        t_o, t_n = timeit(old, iters), timeit(new, iters)
+        print(f"skip   {name:10s} N={N:3d} {H}x{W} {C1}+{C2}->{Cout}: cat + GN + shortcut {t_o * 1e3:6.3f} ms | in place {t_n * 1e3:6.3f} ms")
+    x, w, b = rn(163840, 640), rn(5120, 640) * 640 ** -0.5, rn(5120)
+    wp, bp = K.pack_geglu(w, b)
+    for ng in (1, 2, 4):
+        K.tuning_set("ring_groups", ng)
+        t = timeit(lambda: K.linear_geglu(x, wp, bp, 2560), iters)
+        print(f"groups pers L1 GEGLU 640->5120, {ng} cout group(s): {t * 1e3:6.3f} ms {2.0 * 163840 * 640 * 5120 / t / 1e12:6.0f} TF/s")
+    K.tuning_set("ring_groups", 0)
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 10
