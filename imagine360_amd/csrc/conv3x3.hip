@@ -75,9 +75,10 @@ __device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v))
 //      as operand tiles any more; the caller has passed a workgroup barrier since the last operand read.
 // UP2: the tile's rows are pixels of the LOW-resolution grid [N, Hout, Wout]; row (n, y, x) is stored at pixel
 // (n, 2 y + up2_py, 2 x + up2_px) of the [N, 2 Hout, 2 Wout, Cout] output (sub-pixel form of nearest-x2 + conv3x3).
+// cvec (EPI 3 / 4): the tile's fp32 column vectors staged in LDS by the caller, [0, BN) = c1, [BN, 2 BN) = c2 (+ table row).
 template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
-                                              int wm, int wn, int wid_s, int lane) {
+                                              int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0) {
     const int col = lane & 31, hi = lane >> 5;
     const T* bias = (const T*)p.bias;
     const T* temb = (const T*)p.temb;
@@ -148,9 +149,9 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     f32x2 v01 = {acc[2 * i][b][4 * g], acc[2 * i][b][4 * g + 1]}, v23 = {acc[2 * i][b][4 * g + 2], acc[2 * i][b][4 * g + 3]};
                     f32x2 t01 = {acc[2 * i + 1][b][4 * g], acc[2 * i + 1][b][4 * g + 1]}, t23 = {acc[2 * i + 1][b][4 * g + 2], acc[2 * i + 1][b][4 * g + 3]};
                     if constexpr (EPI == 4) {
-                        const int rv = nw0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows
-                        const f32x4 k1v = *(const f32x4*)(p.ln_c1 + rv), k2v = *(const f32x4*)(p.ln_c2 + rv);
-                        const f32x4 k1g = *(const f32x4*)(p.ln_c1 + rg), k2g = *(const f32x4*)(p.ln_c2 + rg);
+                        const int rv = nw0 - n0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows, relative to the tile
+                        const f32x4 k1v = *(const f32x4*)(cvec + rv), k2v = *(const f32x4*)(cvec + bn + rv);
+                        const f32x4 k1g = *(const f32x4*)(cvec + rg), k2g = *(const f32x4*)(cvec + bn + rg);
                         v01 = (v01 - MU * k1v.xy) * RS + k2v.xy;
                         v23 = (v23 - MU * k1v.zw) * RS + k2v.zw;
                         t01 = (t01 - MU * k1g.xy) * RS + k2g.xy;
@@ -223,8 +224,6 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             // EPI 3: LayerNorm folded into the projection (see ConvParams): mean / rstd of this lane's row from the producer's
             // per-slice (sum, sum of squares); the optional table adds row group (m / tab_div) % tab_mod's fp32 vector
             float ln_mu = 0.f, ln_rstd = 1.f;
-            const float* ln_trow = (const float*)zsrc;
-            uint32_t ln_tmul = 0u;
             if constexpr (EPI == 3) {
                 float ss = 0.f, qq = 0.f;
                 for (int j = 0; j < p.rs_p; ++j) {
@@ -234,10 +233,6 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
                 ln_mu = ss * p.ln_invc;
                 ln_rstd = __builtin_amdgcn_rsqf(fmaxf(qq * p.ln_invc - ln_mu * ln_mu, 0.f) + p.ln_eps);
-                if (p.ln_tab) {
-                    ln_trow = p.ln_tab + ((m / p.tab_div) % p.tab_mod) * (long)p.Cout;
-                    ln_tmul = 1u;
-                }
             }
             // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
             // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
@@ -261,29 +256,19 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 if constexpr (EPI == 3) {
-                    // two register groups at a time: the fp32 vectors of four would not fit next to the accumulators
+                    // the column vectors come from LDS (staged once per tile by the kernel: from global memory the forty
+                    // dependent load rounds of a block cost more than the LayerNorm pass this epilogue replaces)
 #pragma unroll
-                    for (int gh = 0; gh < 2; ++gh) {
-                        f32x4 k1[2], k2[2], kt[2];
+                    for (int g = 0; g < 4; ++g) {
+                        const int cr = nw0 - n0 + a * 32 + 8 * g + 4 * hi;
+                        const f32x4 k1 = *(const f32x4*)(cvec + cr), k2 = *(const f32x4*)(cvec + bn + cr);
+                        float f[4];
 #pragma unroll
-                        for (int g2 = 0; g2 < 2; ++g2) {
-                            const int co = nw0 + a * 32 + 8 * (2 * gh + g2) + 4 * hi;
-                            const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
-                            k1[g2] = *(const f32x4*)(p.ln_c1 + cc);
-                            k2[g2] = *(const f32x4*)(p.ln_c2 + cc);
-                            kt[g2] = *(const f32x4*)(ln_trow + cc * ln_tmul);
-                        }
-#pragma unroll
-                        for (int g2 = 0; g2 < 2; ++g2) {
-                            const int g = 2 * gh + g2;
-                            float f[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) f[j] = (acc[a][b][4 * g + j] - ln_mu * k1[g2][j]) * ln_rstd + (k2[g2][j] + kt[g2][j]);
-                            uint2 o;
-                            o.x = pack2<T>(f[0], f[1]);
-                            o.y = pack2<T>(f[2], f[3]);
-                            *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
-                        }
+                        for (int j = 0; j < 4; ++j) f[j] = (acc[a][b][4 * g + j] - ln_mu * k1[j]) * ln_rstd + k2[j];
+                        uint2 o;
+                        o.x = pack2<T>(f[0], f[1]);
+                        o.y = pack2<T>(f[2], f[3]);
+                        *(uint2*)(wlds + col * ROWB + (((a * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                     }
                 } else {
                 uint2 wb[4], wt[4];
@@ -710,9 +695,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     static_assert((BM * CPR) % NT == 0 && ((BN * CPR) % NT == 0 || (BN * CPR) % NT == NT / 2), "staging pattern");
     constexpr int EPI_ROWB = (EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
-    constexpr int LDS_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
+    constexpr int RING_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
+    constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
+    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : 0);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    float* cvec = (float*)(lds + RING_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, hi = lane >> 5;
@@ -867,6 +855,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int n0 = tile_n0(tile);
         // phase 2 goes into a slot the previous tile's epilogue used: every wave has to be out of it
         asm volatile("s_barrier" ::: "memory");
+        if constexpr (LNF) {
+            // this tile's column vectors -> LDS (read by the epilogue, many barriers from here): threads 0 .. BN/4-1 take c1,
+            // the next BN/4 take c2 + the tile's table row (rows of a 256-row tile share one: tab_div % 256 == 0, host-checked)
+            if (tid < BN / 2) {
+                const int v = tid / (BN / 4), idx = (tid % (BN / 4)) * 4;
+                f32x4 val = *(const f32x4*)((v ? p.ln_c2 : p.ln_c1) + n0 + idx);
+                if (v && p.ln_tab) val += *(const f32x4*)(p.ln_tab + ((m0 / p.tab_div) % p.tab_mod) * (long)p.Cout + n0 + idx);
+                *(f32x4*)(cvec + v * BN + idx) = val;
+            }
+        }
         if (nph > 2) issue(2);
 
         f32x16 acc[TN][TM];
@@ -1044,7 +1042,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e);
+        tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
         if (next >= ntiles) break;
         tile = next;
     }
@@ -1610,7 +1608,7 @@ extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const vo
     IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_ln_fwd: K=%ld must be a positive multiple of 32", (long)K);
     IM360_CHECK_ARG(N > 0 && (N % 320) == 0, "linear_ln_fwd: N=%ld must be a positive multiple of 320", (long)N);
     IM360_CHECK_ARG(rs_p > 0 && rs_p <= 64, "linear_ln_fwd: rs_p=%ld out of range", (long)rs_p);
-    IM360_CHECK_ARG(!tab || (tab_div > 0 && tab_mod > 0), "linear_ln_fwd: tab_div, tab_mod must be positive");
+    IM360_CHECK_ARG(!tab || (tab_div > 0 && tab_mod > 0 && (tab_div % 256) == 0), "linear_ln_fwd: tab_div=%ld must be a positive multiple of 256 (one table row per 256-row tile), tab_mod positive", (long)tab_div);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)c1 % 16) == 0 &&
                     ((uintptr_t)c2 % 16) == 0 && ((uintptr_t)tab % 16) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_ln_fwd: misaligned pointer");
     IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_ln_fwd: dtype %d unsupported", dtype);

@@ -282,11 +282,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
     }
 }
 
-// bias [n] (16-bit) -> fp16 [n] = bias * log2(e): the form attn_fwd's packed-bias kernels feed to the matrix pipe
+// bias [n] (16-bit) -> fp16 [n] = bias * log2(e): the form attn_fwd's packed-bias kernels feed to the matrix pipe.
+// The kernel adds it with an identity-slice MFMA (s += I * bias): a non-finite entry would meet the identity's zeros
+// (0 * inf = NaN for the whole 32 x 32 score block), so -inf / finfo.min style masks are clamped to +-60000 -- exp2 of
+// that is an exact 0 weight all the same; NaN inputs become the clamp value too.
 template <typename T>
 __global__ void attn_pack_bias_kernel(const T* __restrict__ b, _Float16* __restrict__ out, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = (_Float16)(to_f32(b[i]) * 1.4426950408889634f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = to_f32(b[i]) * 1.4426950408889634f;
+        out[i] = (_Float16)fminf(fmaxf(v, -60000.f), 60000.f);       // (fmaxf / fminf return the finite operand for NaN)
+    }
 }
 
 }  // namespace im360

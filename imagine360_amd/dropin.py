@@ -48,8 +48,22 @@ _ALIASES = {
     "src.modules.utils": dict(flush=_flush),
     "src.utils.pano": dict(pad_pano=pano_geometry.pad_pano, unpad_pano=pano_geometry.unpad_pano),
     "diffusers": dict(AutoencoderKL=vae.AutoencoderKL, DDIMScheduler=scheduler.DDIMScheduler),
-    "diffusers.utils.import_utils": dict(is_xformers_available=lambda: True),    # the xformers code path is what the kernels implement
 }
+# ``is_xformers_available`` is answered per CALLER: the reference script and the checkout's own packages see True (the
+# xformers code path -- logit scale d^-1/2 in IPCrossAttention -- is what the kernels implement), everything else (the real
+# diffusers, any third party) keeps the library's own answer: patching the function globally made every later
+# ``if is_xformers_available(): import xformers`` at module scope fail on a box without xformers.
+_XFORMERS_CALLERS = ("__main__", "inference_dual_p2e", "animatediff", "src")
+
+
+def _scoped_xformers_probe(original):
+    def is_xformers_available():
+        caller = sys._getframe(1).f_globals.get("__name__", "")
+        if caller.split(".")[0] in _XFORMERS_CALLERS:
+            return True
+        return bool(original()) if callable(original) else False
+    is_xformers_available.__im360_alias__ = True
+    return is_xformers_available
 # names a synthetic module must also carry when the real one cannot be imported (the script imports them by name)
 _FALLBACK_EXTRAS = {
     "src.utils.pano": dict(icosahedron_sample_camera=synthetic.icosahedron_angles),
@@ -139,6 +153,23 @@ def install(force=False, preprocess=False):
             for k, v in {**attrs, **_FALLBACK_EXTRAS.get(name, {})}.items():
                 setattr(mod, k, v)
             done[name] = "synthetic"
+    # the xformers probe: one scoped function on the module that defines it (later ``from ... import`` pick it up); modules
+    # that already imported the original keep it unless they are the checkout's own
+    iu = sys.modules.get("diffusers.utils.import_utils") or _import_real("diffusers.utils.import_utils")
+    if iu is None or getattr(iu, "__im360_alias__", False):
+        # no diffusers on this box: a synthetic module carrying only the probe (False for everybody but the script's side)
+        iu = iu if iu is not None else _synthetic_module("diffusers.utils.import_utils")
+        iu.is_xformers_available = _scoped_xformers_probe(None)
+        done["diffusers.utils.import_utils"] = "synthetic"
+    elif not getattr(getattr(iu, "is_xformers_available", None), "__im360_alias__", False):
+        orig = getattr(iu, "is_xformers_available", None)
+        probe = _scoped_xformers_probe(orig)
+        _rebind(iu, "is_xformers_available", probe)
+        done["diffusers.utils.import_utils"] = "scoped probe"
+        for mname, mod in list(sys.modules.items()):
+            if isinstance(mod, types.ModuleType) and mname.split(".")[0] in _XFORMERS_CALLERS and orig is not None \
+                    and vars(mod).get("is_xformers_available") is orig:
+                _rebind(mod, "is_xformers_available", probe)
     # modules that already bound the originals by ``from x import Name``
     for mname, mod in list(sys.modules.items()):
         if mod is None or mname.startswith("imagine360_amd") or not isinstance(mod, types.ModuleType):

@@ -54,12 +54,25 @@ PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4,
 STATS = None
 
 
-def _count(kind, flops, nbytes):
+# Launch mix by shape (bench.py weights the measured HBM traffic of tools/hbm_traffic.py with it): None = off, else
+# {(class, shape key): [launches, algorithmic bytes]}
+SHAPES = None
+
+
+def _count(kind, flops, nbytes, executed=None, shape=None):
+    """``flops``: the reference algorithm's flops of the launch; ``executed``: what the kernel actually multiplies when it
+    differs (the sub-pixel upsample convolutions run 4 / 9 of them) -- hardware utilisation is priced on executed flops.
+    ``shape``: a key naming the launch's shape class (token count excluded), for the launch-mix statistics."""
     if STATS is not None:
-        s = STATS.setdefault(kind, [0.0, 0.0, 0])
+        s = STATS.setdefault(kind, [0.0, 0.0, 0, 0.0])
         s[0] += flops
         s[1] += nbytes
         s[2] += 1
+        s[3] += flops if executed is None else executed
+    if SHAPES is not None and shape is not None:
+        h = SHAPES.setdefault((kind, shape), [0, 0.0])
+        h[0] += 1
+        h[1] += nbytes
 
 
 def exported_symbols():
@@ -111,8 +124,9 @@ def _p(t):
 
 # ------------------------------------------------------------------------------------------ attention
 def pack_attn_bias(bias):
-    """bias (16-bit, any shape) -> fp16 ``bias * log2(e)``: the form ``attention(..., bias_packed=True)`` feeds to the
-    matrix pipe (head dim 32, Nk % 8 == 0).  Once per cached mask."""
+    """bias (16-bit, any shape) -> fp16 ``bias * log2(e)`` clamped to +-60000 (finite: -inf masks become an exact zero
+    weight instead of poisoning the identity-slice MFMA that adds them): the form ``attention(..., bias_packed=True)``
+    feeds to the matrix pipe (head dim 32, Nk % 8 == 0).  Once per cached mask."""
     _dev(bias)
     b = bias.contiguous()
     out = torch.empty(b.shape, dtype=torch.float16, device=b.device)
@@ -295,7 +309,8 @@ def conv_up2(x, w4_packed, cout, bias=None, wrap=False):
     y = torch.empty((N, 2 * Hin, 2 * Win, cout), dtype=x.dtype, device=x.device)
     rc = lib().im360_conv_up2_fwd(_p(x), _p(w4_packed), _p(bias), _p(y), N, Hin, Win, Cin, cout, int(wrap), _dt(x), _stream())
     _check(rc, "im360_conv_up2_fwd")
-    _count("conv", 2.0 * N * 4 * Hin * Win * cout * Cin * 9, x.element_size() * (x.numel() + y.numel() + 9 * cout * Cin))
+    _count("conv", 2.0 * N * 4 * Hin * Win * cout * Cin * 9, x.element_size() * (x.numel() + y.numel() + 9 * cout * Cin),
+           executed=2.0 * N * 4 * Hin * Win * cout * Cin * 4, shape=f"up2:{Cin}:{cout}:{2 * Hin}x{2 * Win}{'w' if wrap else ''}")
     return y
 
 
@@ -323,7 +338,9 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
         es = x.element_size()
         linear = taps == 1 and Hin == 1 and Win == 1
         _count("gemm" if linear else "conv", 2.0 * N * hout * wout * Cin * cout * taps,
-               es * (x.numel() + cout * taps * Cin + y.numel() * (2 if res is not None else 1)))
+               es * (x.numel() + cout * taps * Cin + y.numel() * (2 if res is not None else 1)),
+               shape=(f"lin:{Cin}:{cout}:{'res' if res is not None else 'nores'}" if linear else
+                      f"conv{taps}:{Cin}:{cout}:{hout}x{wout}:s{stride}{'u' if up else ''}{'w' if wrap else ''}{'o' if x_off else ''}"))
     return y
 
 
@@ -345,7 +362,8 @@ def conv1x1_cat(xa, xb, w_packed, cout, bias=None, res=None):
                                      _dt(xa), _stream())
     _check(rc, "im360_conv1x1_cat_fwd")
     _count("conv", 2.0 * N * H * W * (C1 + C2) * cout,
-           xa.element_size() * (xa.numel() + xb.numel() + cout * (C1 + C2) + y.numel() * (2 if res is not None else 1)))
+           xa.element_size() * (xa.numel() + xb.numel() + cout * (C1 + C2) + y.numel() * (2 if res is not None else 1)),
+           shape=f"conv1cat:{C1}+{C2}:{cout}:{H}x{W}")
     return y
 
 
@@ -368,7 +386,7 @@ def linear(x, w_packed, n, bias=None, res=None, row_stats=False):
     rc = lib().im360_linear_fwd(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), _p(st), m, k, n, _dt(x), _stream())
     _check(rc, "im360_linear_fwd")
     _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel() * (2 if res is not None else 1))
-           + (0 if st is None else 4 * st.numel()))
+           + (0 if st is None else 4 * st.numel()), shape=f"lin{'+stats' if row_stats else ''}:{k}:{n}:{'res' if res is not None else 'nores'}")
     return (y, st) if row_stats else y
 
 
@@ -388,7 +406,7 @@ def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1):
     rc = lib().im360_linear_ln_fwd(_p(x), _p(w_packed), _p(c1), _p(c2), _p(stats), stats.shape[1], float(eps), _p(tab),
                                    tab_div, tab.shape[0] if tab is not None else 1, _p(y), m, k, n, _dt(x), _stream())
     _check(rc, "im360_linear_ln_fwd")
-    _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel()) + 4 * stats.numel())
+    _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel()) + 4 * stats.numel(), shape=f"lin_ln:{k}:{n}")
     return y
 
 
@@ -406,7 +424,8 @@ def linear_geglu_ln(x, w_packed, c1, c2, stats, eps, inner):
     rc = lib().im360_linear_geglu_ln(_p(x), _p(w_packed), _p(c1), _p(c2), _p(stats), stats.shape[1], float(eps), _p(y),
                                      m, k, inner, _dt(x), _stream())
     _check(rc, "im360_linear_geglu_ln")
-    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()) + 4 * stats.numel())
+    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()) + 4 * stats.numel(),
+           shape=f"geglu_ln:{k}:{inner}")
     return y
 
 
@@ -485,7 +504,7 @@ def linear_geglu(x, w_packed, bias_packed, inner):
     y = torch.empty(x.shape[:-1] + (inner,), dtype=x.dtype, device=x.device)
     rc = lib().im360_linear_geglu(_p(x), _p(w_packed), _p(bias_packed), _p(y), m, k, inner, _dt(x), _stream())
     _check(rc, "im360_linear_geglu")
-    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()))
+    _count("gemm", 2.0 * m * k * 2 * inner, x.element_size() * (x.numel() + 2 * inner * k + y.numel()), shape=f"geglu:{k}:{inner}")
     return y
 
 
@@ -502,6 +521,11 @@ def softmax_rows(x, scale=1.0, out=None):
     return out
 
 
+def can_single_head_attention(d, nk):
+    """Shapes ``single_head_attention`` takes (GEMM K / softmax row granularity); callers keep a torch path for the rest."""
+    return d % 32 == 0 and nk % 32 == 0
+
+
 def single_head_attention(q, k, v, scale):
     """softmax(q k^T * scale) v for ONE head of any width (the VAE's d = 512 AttentionBlock): scores through the MFMA
     GEMM kernel (k as the weight operand), fp32 row softmax of the 16-bit scores, probabilities x v through the GEMM
@@ -509,11 +533,13 @@ def single_head_attention(q, k, v, scale):
     336-364).  q [Nq, d], k / v [Nk, d]; d % 32 == 0, Nk % 32 == 0."""
     nq, d = q.shape
     nk = k.shape[0]
-    if d % 32 or nk % 32:
+    if not can_single_head_attention(d, nk):
         raise NotImplementedError(f"single_head_attention: d={d} and Nk={nk} must be multiples of 32")
     kw = k.contiguous().reshape(nk, 1, d) if nk % 128 == 0 else pack_conv_weight(k.reshape(nk, d, 1, 1))
-    s = conv2d(q.contiguous().reshape(nq, 1, 1, d), kw, nk).reshape(nq, nk)
-    softmax_rows(s, scale, out=s)
+    # the scale goes into q BEFORE the GEMM, so the 16-bit scores that are stored are the scaled ones -- like the reference's
+    # baddbmm(alpha=scale); unscaled d = 512 dot products would cost fp16 a factor sqrt(512) of headroom before inf
+    s = conv2d((q * scale).contiguous().reshape(nq, 1, 1, d), kw, nk).reshape(nq, nk)
+    softmax_rows(s, 1.0, out=s)
     vt = v.t().contiguous()
     vw = vt.reshape(d, 1, nk) if d % 128 == 0 else pack_conv_weight(vt.reshape(d, nk, 1, 1))
     return conv2d(s.reshape(nq, 1, 1, nk), vw, d).reshape(nq, d)

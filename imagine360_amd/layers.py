@@ -153,7 +153,7 @@ def ln_linear(norm, weight, bias, x, stats, cache, key, post=None, post_div=1):
     LayerNorm pass over the activations and its output tensor disappear; without them: LayerNorm kernel + ``gemm_linear``."""
     n, k = weight.shape
     m = x.numel() // k
-    if stats is None or not _routed(x, m, k, n):
+    if stats is None or not _routed(x, m, k, n) or (post is not None and post_div % 256):      # (the kernel adds one table row per 256-row tile)
         return gemm_linear(weight, bias, layer_norm(norm, x, post=post, post_div=post_div), cache=cache, key=key)
 
     def build():

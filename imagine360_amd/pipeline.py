@@ -148,7 +148,9 @@ class AnimationPipeline:
         gives the same numbers with 1/8 of the launches."""
         b, c, f, h, w = latents.shape
         z = (latents / VAE_SCALE).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
-        frames = [self.vae.decode(z[i:i + frames_per_call].to(self.vae.dtype), batched=True).sample
+        import inspect
+        kw = {"batched": True} if "batched" in inspect.signature(self.vae.decode).parameters else {}     # (a user-supplied diffusers VAE has no such keyword)
+        frames = [self.vae.decode(z[i:i + frames_per_call].to(self.vae.dtype), **kw).sample
                   for i in range(0, z.shape[0], frames_per_call)]
         video = torch.cat(frames).reshape(b, f, 3, h * 8, w * 8).permute(0, 2, 1, 3, 4)
         return (video / 2 + 0.5).clamp(0, 1).cpu().float().numpy()

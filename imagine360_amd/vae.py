@@ -53,8 +53,14 @@ class AttentionBlock(nn.Module):
         n, h, w, c = x.shape
         t = self.group_norm.forward_cl(x).reshape(n, h * w, c)
         q, k, v = self.query(t), self.key(t), self.value(t)
-        # one head of width c (512): QK^T and PV on the MFMA GEMM kernel, fp32 row softmax between them, per image
-        out = torch.stack([kernels.single_head_attention(q[i], k[i], v[i], c ** -0.5) for i in range(n)])
+        if kernels.can_single_head_attention(c, h * w):
+            # one head of width c (512): QK^T and PV on the MFMA GEMM kernel, fp32 row softmax between them, per image
+            out = torch.stack([kernels.single_head_attention(q[i], k[i], v[i], c ** -0.5) for i in range(n)])
+        else:
+            # token counts the GEMM kernel does not tile (e.g. a 360 x 640 frame: 45 x 80 = 3600 tokens): the reference's own
+            # op sequence, baddbmm(alpha = scale) -> softmax(float) -> bmm (diffusers/models/attention.py:336-364), on rocBLAS
+            s = torch.baddbmm(torch.empty(n, h * w, h * w, dtype=q.dtype, device=q.device), q, k.transpose(1, 2), beta=0, alpha=c ** -0.5)
+            out = torch.bmm(torch.softmax(s.float(), dim=-1).to(q.dtype), v)
         return self.proj_attn(out).reshape(n, h, w, c) + x
 
 

@@ -38,8 +38,10 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
                    const void* bias_alt, const void* bias_sel);
 
-/* out_f16[i] = fp16(bias[i] * log2(e)) for the n elements of a bias matrix of dtype 0 / 1: the packed form accepted by
- * im360_attn_fwd with dtype + 256.  Done once per (resolution, camera rig) -- WarpAttn's masks are cached. */
+/* out_f16[i] = fp16(clamp(bias[i] * log2(e), -60000, 60000)) for the n elements of a bias matrix of dtype 0 / 1: the packed
+ * form accepted by im360_attn_fwd with dtype + 256.  The packed entries must be FINITE (the kernel adds them with an
+ * identity-slice MFMA, where 0 * inf would poison the whole score block): this function guarantees it by clamping, so -inf
+ * masks are usable (weight exactly 0).  Done once per (resolution, camera rig) -- WarpAttn's masks are cached. */
 int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, void* stream);
 
 /* Two key / value sets for the same queries in one launch (head dim 64, no bias):
@@ -184,8 +186,8 @@ int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, cons
  * (sum, sum of squares) slices from im360_linear_fwd, w_packed = pack(gamma (.) W) and
  *   y[r] = rstd_r * (x[r] w^T - mu_r * c1) + c2 (+ tab[(r / tab_div) % tab_mod])
  * with fp32 vectors c1[n] = sum_k w'[n][k] (of the rounded 16-bit w'), c2 = W beta + bias; tab (optional, fp32
- * [tab_mod][N]): rows added AFTER the normalisation pushed through the projection (the motion module's frame positional
- * encoding).  The LayerNorm pass over the activations and its output tensor do not exist.  Variance = E[x^2] - mu^2 in
+ * [tab_mod][N], tab_div % 256 == 0): rows added AFTER the normalisation pushed through the projection (the motion module's
+ * frame positional encoding; one table row per 256-row tile).  The LayerNorm pass over the activations and its output tensor do not exist.  Variance = E[x^2] - mu^2 in
  * fp32 from 16-bit data.  N % 320 == 0, K % 32 == 0.
  * Replaces: nn.LayerNorm -> to_q / fused to_q,k,v, animatediff/models/attention.py:470-488; motion_module.py:236-250
  *   (+ pos_encoder :349-350). */

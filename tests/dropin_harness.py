@@ -54,6 +54,11 @@ for k, v in dict(imread=None, resize=None, cvtColor=None, COLOR_BGR2RGB=4, COLOR
 from imagine360_amd import configs, dropin, mv_model, pipeline, scheduler, unet3d, vae  # noqa: E402
 import _emu_kernels as E  # noqa: E402
 
+try:
+    from diffusers.utils.import_utils import is_xformers_available as _library_probe
+    _library_answer = bool(_library_probe())          # (True under ref_shims: it registers an xformers stand-in)
+except Exception:          # noqa: BLE001
+    _library_answer = None
 how = dropin.install()
 
 src_path = os.path.join(ref_shims.REF_ROOT, "inference_dual_p2e.py")
@@ -62,6 +67,18 @@ ref.__file__ = src_path
 exec(compile(open(src_path).read(), src_path, "exec"), ref.__dict__)          # __name__ != "__main__": defines, does not run
 
 out = {"how": how}
+# a diffusers submodule imported AFTER the overlay must see the library's own xformers probe (False here: no xformers), not
+# the overlay's True -- its module-level `if is_xformers_available(): import xformers` would raise otherwise
+import importlib  # noqa: E402
+
+for _m in [m for m in list(sys.modules) if m.startswith("diffusers.models.attention_processor")]:
+    del sys.modules[_m]
+try:
+    _ap = importlib.import_module("diffusers.models.attention_processor")
+    out["fresh_diffusers_import"] = {"ok": True, "library_answer": _library_answer,
+                                     "probe_for_diffusers": bool(eval("is_xformers_available()", vars(_ap))) if hasattr(_ap, "is_xformers_available") else None}      # (called from inside the module)
+except Exception as e:          # noqa: BLE001
+    out["fresh_diffusers_import"] = {"ok": False, "error": repr(e)}
 out["names"] = {
     "AutoencoderKL": ref.AutoencoderKL is vae.AutoencoderKL,
     "DDIMScheduler": ref.DDIMScheduler is scheduler.DDIMScheduler,

@@ -90,6 +90,10 @@ def test_folded_layernorm_and_skip_pair_paths_against_reference(mv):
         assert calls.count("linear_ln") == 2 and calls.count("linear_geglu_ln") == 1 and calls.count("linear") == 3, calls
         del calls[:]
         assert rel(un.down_blocks[0].motion_modules[0](I["x"], I["emb"], I["ctx"]), g["motion"]) < TOL
+        assert calls.count("linear_ln") == 0 and calls.count("linear_geglu_ln") == 1, calls      # 128 pixels per frame: the PE table needs 256 | pixels
+        xm = torch.randn(1, 64, 4, 16, 16, generator=torch.Generator().manual_seed(3))        # 256 pixels per frame: QKV folded too, PE as a table
+        del calls[:]
+        folded = un.down_blocks[0].motion_modules[0](xm, None, None)
         assert calls.count("linear_ln") == 2 and calls.count("linear_geglu_ln") == 1, calls
         x2 = torch.cat([I["x"], I["x"].flip(1), 0.5 * I["x"].roll(3, 1)], 1)
         xa, _ = to_cl(x2[:, :128])
@@ -102,6 +106,8 @@ def test_folded_layernorm_and_skip_pair_paths_against_reference(mv):
         del calls[:]
         p, e = mv.cp_blocks_encoder[0](I["px"], I["ex"], cams)
         assert rel(p, g["warp_pers_normal"]) < TOL and rel(e, g["warp_equi_normal"]) < TOL and calls.count("linear_geglu_ln") == 2
+    with E.patched_kernels():
+        assert rel(folded, un.down_blocks[0].motion_modules[0](xm, None, None)) < 2e-5          # == LayerNorm kernel + PE add + GEMM
     inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=0, sam_frames=16)
     cams = S.icosahedron_cameras(90, 128)
     mv.unet.disable_xformers_memory_efficient_attention()
@@ -265,7 +271,8 @@ def test_dropin_aliases():
         import imagine360_amd.unet3d as U3
         assert UNet3DConditionModel is U3.UNet3DConditionModel and callable(pad_pano) and callable(unpad_pano)
         assert AnimationPipeline.__call__ and AutoencoderKL and DDIMScheduler and MultiViewBaseModel
-        assert is_xformers_available() and flush() is None
+        assert flush() is None and not is_xformers_available()       # answered per caller: this test module is not the script ...
+        assert eval("is_xformers_available()", {"__name__": "__main__", "is_xformers_available": is_xformers_available})   # ... the script is
     finally:
         dropin.uninstall()
     assert "animatediff.models.unet" not in sys.modules and "diffusers" not in sys.modules
@@ -285,8 +292,12 @@ def test_dropin_overlay_runs_the_reference_script():
     r = subprocess.run([sys.executable, os.path.join(here, "dropin_harness.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert set(out["how"].values()) == {"overlay"}
+    assert out["how"].pop("diffusers.utils.import_utils") == "scoped probe" and set(out["how"].values()) == {"overlay"}
     assert all(out["names"].values()), out["names"]
+    # the xformers probe is answered per caller: True for the script (above), the library's own answer for diffusers modules
+    # imported after the overlay (on a box without xformers their module-level `import xformers` must not run)
+    fd = out["fresh_diffusers_import"]
+    assert fd["ok"] and fd["probe_for_diffusers"] == fd["library_answer"], fd
     b = out["built"]
     assert all(t.startswith("imagine360_amd.") for t in b["types"])
     assert b["conv_in_widened"][1] == 9 and b["conv_in_extra_channels_zero"] and b["motion_ckpt_loaded"]
