@@ -54,7 +54,13 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // the scores through the matrix pipe -- two f16 MFMAs per 32 x 32 score block with a 32 x 16 slice of the identity as the
 // A operand and 16 bytes of a bias row as the B operand -- instead of 16 unpack + 16 FMA VALU instructions per lane and
 // block.  WarpAttn (d = 32) does half the MFMA work of d = 64 per score on the same softmax VALU work and is VALU-bound.
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false>
+// BL ("bias through LDS", BF with two query blocks): a lane's mask fragment is 16 bytes of ITS query row, so a fragment load
+// straight from global memory touches 64 different cache lines per instruction -- and the vector memory path looks up one
+// line per cycle: eight such loads per 64-key tile and wave are ~500 cycles of address processing against ~1300 cycles of
+// VALU work per SIMD, on a path shared by the CU's eight waves.  With BL the wave fetches its 64 rows x 64 bytes of the next
+// 32-key half COALESCED (four lanes per row segment: 16 lines per instruction), parks them in its own 4 KiB of LDS
+// (XOR-swizzled, conflict-free both ways) and reads the per-lane fragments from there.
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
@@ -74,6 +80,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // double-buffered K / V tiles: one barrier per KV tile (the next tile is written while this one is consumed)
     __shared__ __attribute__((aligned(16))) T k_lds2[2 * KT];
     __shared__ __attribute__((aligned(16))) T v_lds2[2 * VT];
+    constexpr bool BF_LDS = BF && QB > 1 && BL;
+    constexpr int BROWS = 32 * QB;             // mask rows of one wave
+    constexpr int BLD = BROWS * 4 / 64;        // 16-byte loads per lane and 32-key half (4 lanes per 64-byte row segment)
+    __shared__ __attribute__((aligned(16))) uint4 b_lds[BF_LDS ? NW * BROWS * 4 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -197,11 +207,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // BF with two query blocks per wave: the mask fragments of a 32-key half are requested ONE HALF AHEAD into the other of
     // two register buffers (the buffer index is the half's parity, a compile-time constant): requested right in front of
     // the two QK^T MFMAs that precede their use, their L2 latency stalled every half tile (SQ_WAIT_ANY 60 %).
-    constexpr bool BF_AHEAD = BF && QB > 1;
-    uint4 bfh[2][BF_AHEAD ? QB : 1][2];
+    constexpr bool BF_AHEAD = BF && QB > 1 && !BL;
+    uint4 bfh[2][(BF_AHEAD || BF_LDS) ? QB : 1][2];
+    u32x4 breg[BF_LDS ? BLD : 1];
+    const int brow = lane >> 2, bch = lane & 3;      // BL loader: instruction i covers mask rows 16 i + brow, 16-byte chunk bch
+    uint4* const bw_lds = b_lds + (BF_LDS ? wid * BROWS * 4 : 0);
     auto fetch_half = [&](int key_base, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if constexpr (BF_AHEAD) {
+        if constexpr (BF_LDS) {
+            // global -> registers, one 32-key half ahead of its use
+            const int key0 = min(key_base + bch * 8, set_nk - 8);
+#pragma unroll
+            for (int i = 0; i < BLD; ++i) {
+                const int row = min(q0 + i * 16 + brow, p.Nq - 1);
+                breg[i] = *(const u32x4*)(bias + (long)row * p.bias_rs + key0);
+            }
+        } else if constexpr (BF_AHEAD) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -224,7 +245,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         uint4 bfm[BF ? QB : 1][2][2];          // BF: [query block][half][16-key chunk]: keys 16 c + 8 hi .. + 7 of the lane's query row
         auto load_bias = [&](auto kbc) {
             constexpr int kb = decltype(kbc)::value;
-            if constexpr (BF_AHEAD) {
+            if constexpr (BF_LDS) {
+                // this half's rows (requested one half ago) -> the wave's LDS patch, row r chunk c at slot c ^ ((r >> 1) & 3);
+                // then every lane picks the two fragments of its query row in each block; the next half is requested
+#pragma unroll
+                for (int i = 0; i < BLD; ++i) {
+                    const int r = i * 16 + brow;
+                    *(u32x4*)&bw_lds[r * 4 + (bch ^ ((r >> 1) & 3))] = breg[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int r = qb * 32 + col;
+                        bfh[0][qb][c] = bw_lds[r * 4 + ((2 * c + hi) ^ ((r >> 1) & 3))];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 0>{});
+            } else if constexpr (BF_AHEAD) {
                 // this half's fragments are already in bfh[kb]; request the next half (of this tile or the next one)
                 fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 1 - kb>{});
             } else if constexpr (BF) {
@@ -264,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
-                        s[qb][kb] = Elem<_Float16>::mfma32(idA[c], BF_AHEAD ? bfh[kb][BF_AHEAD ? qb : 0][c] : bfm[qb][QK_ALL ? kb : 0][c], s[qb][kb]);
+                        s[qb][kb] = Elem<_Float16>::mfma32(idA[c], BF_LDS ? bfh[0][BF_LDS ? qb : 0][c] : (BF_AHEAD ? bfh[kb][BF_AHEAD ? qb : 0][c] : bfm[qb][QK_ALL ? kb : 0][c]), s[qb][kb]);
             }
         };
         // online-softmax update of block qb over the halves [K0, K1), then O^T += V^T P^T for them
@@ -482,7 +522,8 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
             if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, true, false, true>), grid, dim3(64), 0, stream, p);
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
+            else if (knob(KNOB_ATTN_HL) == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);      // A/B: fragments straight from global memory
+            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }

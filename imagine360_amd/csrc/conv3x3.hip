@@ -119,26 +119,37 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 bt[i][g][1] = f32x2{unpack_lo<T>(wg.y), unpack_hi<T>(wg.y)};
             }
         }
+        // EPI 4: LayerNorm folded into the projection -- the accumulators hold x W'^T of the RAW rows (W' = gamma (.) W);
+        // with the row's mean / rstd from the producer's statistics, value = rstd * (acc - mu * c1) + c2 (fp32 vectors in
+        // packed row order: c1 = row sums of W', c2 = W beta + bias).  The statistics of this lane's row in every block are
+        // requested up front (one memory latency for the tile instead of one per block).
+        float ln_mu[TM], ln_rs[TM];
+        if constexpr (EPI == 4) {
+            float ss[TM], qq[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const long mr = m0 + wm * (TM * 32) + b * 32 + col;
+                const long mrow = mr < p.M ? mr : p.M - 1;
+                ss[b] = qq[b] = 0.f;
+                for (int j = 0; j < p.rs_p; ++j) {
+                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
+                    ss[b] += v.x;
+                    qq[b] += v.y;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                ln_mu[b] = ss[b] * p.ln_invc;
+                ln_rs[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - ln_mu[b] * ln_mu[b], 0.f) + p.ln_eps);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const long mb = m0 + wm * (TM * 32) + b * 32;
-            // EPI 4: LayerNorm folded into the projection -- the accumulators hold x W'^T of the RAW rows (W' = gamma (.) W);
-            // with the row's mean / rstd from the producer's statistics, value = rstd * (acc - mu * c1) + c2 (fp32 vectors in
-            // packed row order: c1 = row sums of W', c2 = W beta + bias)
             f32x2 MU = {0.f, 0.f}, RS = {1.f, 1.f};
             if constexpr (EPI == 4) {
-                const long mrow = mb + col < p.M ? mb + col : p.M - 1;
-                float ss = 0.f, qq = 0.f;
-                for (int j = 0; j < p.rs_p; ++j) {
-                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
-                    ss += v.x;
-                    qq += v.y;
-                }
-                const float mu = ss * p.ln_invc;
-                const float var = fmaxf(qq * p.ln_invc - mu * mu, 0.f);
-                const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
-                MU = f32x2{mu, mu};
-                RS = f32x2{rstd, rstd};
+                MU = f32x2{ln_mu[b], ln_mu[b]};
+                RS = f32x2{ln_rs[b], ln_rs[b]};
             }
 #pragma unroll
             for (int i = 0; i < TN / 2; ++i)
@@ -212,6 +223,28 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         const uint32_t bmul = bias ? 2u : 0u, tmul = temb ? 2u : 0u, rmul = res ? 2u : 0u;      // bytes per element, or 0
         const int cmax4 = p.Cout - 4, cmax8 = p.Cout - 8;
         const long hw = (long)p.Hout * p.Wout;
+        // EPI 3: LayerNorm folded into the projection (see ConvParams): mean / rstd of this lane's row in every block from the
+        // producer's per-slice (sum, sum of squares), all requested up front (one memory latency per tile, not one per block)
+        float ln_mus[EPI == 3 ? TM : 1], ln_rstds[EPI == 3 ? TM : 1];
+        if constexpr (EPI == 3) {
+            float ss[TM], qq[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const long mr = m0 + wm * (TM * 32) + b * 32 + col;
+                const long mrow = mr < p.M ? mr : p.M - 1;
+                ss[b] = qq[b] = 0.f;
+                for (int j = 0; j < p.rs_p; ++j) {
+                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
+                    ss[b] += v.x;
+                    qq[b] += v.y;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                ln_mus[b] = ss[b] * p.ln_invc;
+                ln_rstds[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - ln_mus[b] * ln_mus[b], 0.f) + p.ln_eps);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
             const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block (wave-uniform)
@@ -221,18 +254,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             char* ybase = (char*)(yg + mb * p.Cout);
             const long m = mb + (col < rows ? col : rows - 1);
             const uint32_t toff = (uint32_t)((m / hw) / p.imgs_per_temb) * (uint32_t)p.Cout;   // temb row of this lane's pixel
-            // EPI 3: LayerNorm folded into the projection (see ConvParams): mean / rstd of this lane's row from the producer's
-            // per-slice (sum, sum of squares); the optional table adds row group (m / tab_div) % tab_mod's fp32 vector
             float ln_mu = 0.f, ln_rstd = 1.f;
             if constexpr (EPI == 3) {
-                float ss = 0.f, qq = 0.f;
-                for (int j = 0; j < p.rs_p; ++j) {
-                    const f32x2 v = *(const f32x2*)(p.rs_in + (m * p.rs_p + j) * 2);
-                    ss += v.x;
-                    qq += v.y;
-                }
-                ln_mu = ss * p.ln_invc;
-                ln_rstd = __builtin_amdgcn_rsqf(fmaxf(qq * p.ln_invc - ln_mu * ln_mu, 0.f) + p.ln_eps);
+                ln_mu = ln_mus[b];
+                ln_rstd = ln_rstds[b];
             }
             // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
             // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work

@@ -68,6 +68,11 @@ def bench_attn_variants(iters):
             K.tuning_set("attn_qb", qb)
             t = timeit(lambda: K.attention(q, k, v, H, bias=pbb, bias_packed=True), iters)
             row.append(f"packed bias QB={qb}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
+        K.tuning_set("attn_qb", 2)
+        K.tuning_set("attn_hl", 1)          # A/B: mask fragments straight from global memory (round 2) vs through the wave's LDS patch
+        t = timeit(lambda: K.attention(q, k, v, H, bias=pbb, bias_packed=True), iters)
+        row.append(f"packed QB=2, fragments from global memory: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
+        K.tuning_set("attn_hl", 0)
         K.tuning_set("attn_qb", 0)
         print(f"attn  {name:14s} " + " | ".join(row))
     for name, B, H, Nq, Nk in [("pano L0 self d64", 32, 5, 8192, 8192), ("pers L0 self d64", 640, 5, 1024, 1024)]:
