@@ -302,11 +302,12 @@ def main():
 
     prof_kinds = ["conv", "gemm", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
     graphed = None
-    if not args.no_graph and shard is None:
-        # the step is ~3000 launches: capture it once (hipGraph) and replay, so the host is out of the loop
+    if not args.no_graph and (shard is None or os.environ.get("IM360_GRAPH_SHARDED", "1") != "0"):
+        # the step is ~3000 launches (+ 128 all-to-alls in the frame modes): capture it once (hipGraph) and replay, so the
+        # host is out of the loop; the frame-sharded exchanges are RCCL stream operations on pre-sized buffers
         from imagine360_amd.graph_step import GraphedDenoiseStep
         try:
-            graphed = GraphedDenoiseStep(mv, sch, inp, cams, pano_lat, pers_lat, guidance, warmup=1)
+            graphed = GraphedDenoiseStep(mv, sch, inp, cams, pano_lat, pers_lat, guidance, warmup=1, cfg_pair=pair)
         except RuntimeError as e:           # capture refused (e.g. by another runtime thread): time the eager issue instead
             print(f"[rank {rank}] hipGraph capture failed, falling back to eager launches: {e}", file=sys.stderr)
             graphed = None

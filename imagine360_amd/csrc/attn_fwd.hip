@@ -54,12 +54,12 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // the scores through the matrix pipe -- two f16 MFMAs per 32 x 32 score block with a 32 x 16 slice of the identity as the
 // A operand and 16 bytes of a bias row as the B operand -- instead of 16 unpack + 16 FMA VALU instructions per lane and
 // block.  WarpAttn (d = 32) does half the MFMA work of d = 64 per score on the same softmax VALU work and is VALU-bound.
-// BL ("bias through LDS", BF with two query blocks): a lane's mask fragment is 16 bytes of ITS query row, so a fragment load
-// straight from global memory touches 64 different cache lines per instruction -- and the vector memory path looks up one
-// line per cycle: eight such loads per 64-key tile and wave are ~500 cycles of address processing against ~1300 cycles of
-// VALU work per SIMD, on a path shared by the CU's eight waves.  With BL the wave fetches its 64 rows x 64 bytes of the next
-// 32-key half COALESCED (four lanes per row segment: 16 lines per instruction), parks them in its own 4 KiB of LDS
-// (XOR-swizzled, conflict-free both ways) and reads the per-lane fragments from there.
+// BL ("bias through LDS", BF with two query blocks; knob attn_hl = 2, off by default): a lane's mask fragment is 16 bytes of
+// ITS query row, so a fragment load straight from global memory touches 64 different cache lines per instruction.  With BL
+// the wave fetches its 64 rows x 64 bytes of the next 32-key half COALESCED (four lanes per row segment: 16 lines per
+// instruction), parks them in its own 4 KiB of LDS (XOR-swizzled, conflict-free both ways) and reads the per-lane fragments
+// from there.  Measured on WarpAttn level 1: 1.016 vs 0.958 ms -- the divergent loads are NOT what limits the kernel (the
+// hypothesis was one cache-line lookup per cycle on the vector memory path); kept as an A/B variant, identical bits.
 template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
@@ -522,8 +522,8 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
             if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, true, false, true>), grid, dim3(64), 0, stream, p);
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
-            else if (knob(KNOB_ATTN_HL) == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);      // A/B: fragments straight from global memory
-            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);
+            else if (knob(KNOB_ATTN_HL) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);      // A/B: mask rows through the wave's LDS patch (measured 6 % slower: the divergent fragment loads are not the limiter)
+            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }

@@ -294,7 +294,47 @@ __global__ void attn_pack_bias_kernel(const T* __restrict__ b, _Float16* __restr
     }
 }
 
+// Frame-sharded tokens [B, Fl, P, C] <-> the send / receive layout of the frame <-> pixel all-to-all of the motion
+// modules, [W][Fl][B][PP][C] (W ranks, PP = ceil(P / W) pixels per rank, the last rank's tail zero-filled): 16-byte
+// chunks, one per thread, grid-stride.  dir 0: pack (tokens -> exchange buffer), 1: unpack.
+__global__ void shard_pack_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int B, int Fl, int P, int C8,
+                                  int W, int PP, int dir) {
+    const long total = (long)W * Fl * B * PP * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8);
+        long t = i / C8;
+        const int pi = (int)(t % PP); t /= PP;
+        const int b = (int)(t % B); t /= B;
+        const int j = (int)(t % Fl);
+        const int r = (int)(t / Fl);
+        const int pix = r * PP + pi;
+        const long tok = (((long)b * Fl + j) * P + pix) * C8 + c;
+        if (dir == 0) dst[i] = pix < P ? src[tok] : uint4{0u, 0u, 0u, 0u};
+        else if (pix < P) dst[tok] = src[i];
+    }
+}
+
 }  // namespace im360
+
+// tokens [B, Fl, P, C] (16-bit, C % 8 == 0) <-> exchange buffer [W, Fl, B, PP, C] with W * PP >= P (see the kernel).
+// Replaces: nothing in the reference (it is single-process); this is the pack / unpack of the frame-chunk sharding's
+// all-to-all around VersatileAttention (animatediff/models/motion_module.py:343-429), one launch instead of pad + permute +
+// contiguous copies, writing into caller-owned (pre-sized) buffers so the exchange can be captured in a hipGraph.
+extern "C" int im360_shard_pack(const void* src, void* dst, int64_t B, int64_t Fl, int64_t P, int64_t C, int64_t W,
+                                int64_t PP, int dir, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(src && dst, "shard_pack: null pointer");
+    IM360_CHECK_ARG(B > 0 && Fl > 0 && P > 0 && C > 0 && (C % 8) == 0 && W > 0 && PP > 0 && W * PP >= P && (W - 1) * PP < P,
+                    "shard_pack: bad shape B=%ld Fl=%ld P=%ld C=%ld W=%ld PP=%ld", (long)B, (long)Fl, (long)P, (long)C, (long)W, (long)PP);
+    IM360_CHECK_ARG(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "shard_pack: misaligned pointer");
+    IM360_CHECK_ARG(dir == 0 || dir == 1, "shard_pack: dir must be 0 (pack) or 1 (unpack)");
+    const long total = W * Fl * B * PP * (C / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(shard_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
+                       (int)B, (int)Fl, (int)P, (int)(C / 8), (int)W, (int)PP, dir);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
 
 // y[r] = LN(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod]; pre/post optional
 extern "C" int im360_layernorm(const void* x, const void* gamma, const void* beta, const void* pre, const void* post,

@@ -124,27 +124,58 @@ class FrameShard:
         dist.all_gather(parts, x.contiguous(), group=self.group)
         return torch.cat(parts, dim=dim)
 
-    # tokens are [B, F_local, P, C] (frame-sharded)  <->  [B, F_total, P / world, C] (pixel-sharded)
-    def frames_to_pixels(self, x):
-        b, fl, p, c = x.shape
-        w = self.world
-        if w == 1:
-            return x
-        pp = -(-p // w)                                   # pixels per rank, last rank zero-padded
-        if pp * w != p:
-            x = torch.nn.functional.pad(x, (0, 0, 0, pp * w - p))
-        send = x.reshape(b, fl, w, pp, c).permute(2, 0, 1, 3, 4).contiguous()          # [w, b, fl, pp, c]
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv.permute(1, 0, 2, 3, 4).reshape(b, w * fl, pp, c)                    # frames ordered by source rank
+    # ---- frame-sharded tokens [B, Fl, P, C]  <->  pixel-sharded tokens of ALL frames, layout [F_total, B, PP, C] ----------
+    # One all-to-all each way per motion-module attention.  The buffers are pre-sized and cached per shape (stable
+    # addresses: with RCCL the exchange can be captured in a hipGraph); pack / unpack are ONE kernel each
+    # (kernels.shard_pack) and the receive buffer is consumed in place by the temporal-attention kernel through its frame /
+    # batch strides (``kernels.temporal_attention(..., frame_major=True)``), which writes the return trip's send buffer.
+    def pixels_per_rank(self, pixels):
+        return -(-pixels // self.world)
 
-    def pixels_to_frames(self, y, pixels):
-        b, f, pp, c = y.shape
-        w, fl = self.world, self.local
+    def _buf(self, tag, shape, like):
+        key = (tag, tuple(shape), like.dtype, like.device)
+        cache = self.__dict__.setdefault("_buffers", {})
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return cache[key]
+
+    def exchange(self, send, tag):
+        """all_to_all of a [W, ...] buffer along its first axis into a cached receive buffer.  RCCL: device to device over
+        xGMI; gloo (the CPU tests, and the single-GPU test where two ranks share one device): staged through the host."""
+        recv = self._buf(tag, send.shape, send)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            h_send = send.cpu()
+            h_recv = torch.empty_like(h_send)
+            dist.all_to_all_single(h_recv, h_send, group=self.group)
+            recv.copy_(h_recv)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def frames_to_pixels(self, x):
+        """x [B, Fl, P, C] (this rank's frames) -> [F_total * B * PP, C]: this rank's PP pixels of EVERY frame, rows ordered
+        (frame, batch, pixel); pixels past P (last rank) are zero rows."""
+        from . import kernels
+        b, fl, p, c = x.shape
+        w, pp = self.world, self.pixels_per_rank(p)
         if w == 1:
-            return y
-        send = y.reshape(b, w, fl, pp, c).permute(1, 0, 2, 3, 4).contiguous()           # [w, b, fl, pp, c]
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
-        out = recv.permute(1, 2, 0, 3, 4).reshape(b, fl, w * pp, c)
-        return out[:, :, :pixels]
+            return x.permute(1, 0, 2, 3).reshape(fl * b * p, c).contiguous()
+        send = kernels.shard_pack(x.contiguous(), self._buf("f2p_send", (w, fl, b, pp, c), x), b, fl, p, w, pp)
+        return self.exchange(send, "f2p_recv").reshape(w * fl * b * pp, c)
+
+    def pixel_result_buffer(self, like, batch, pixels, channels):
+        """The send buffer of the return trip, [W, Fl, B, PP, C] viewed as rows (frame, batch, pixel): the attention kernel
+        writes its result straight into it."""
+        pp = self.pixels_per_rank(pixels)
+        return self._buf("p2f_send", (self.world, self.local, batch, pp, channels), like).reshape(-1, channels)
+
+    def pixels_to_frames(self, y, batch, pixels):
+        """y [F_total * B * PP, C] (rows (frame, batch, pixel), e.g. ``pixel_result_buffer``) -> [B, Fl, P, C] of this rank's frames."""
+        from . import kernels
+        c = y.shape[-1]
+        w, fl, pp = self.world, self.local, self.pixels_per_rank(pixels)
+        if w == 1:
+            return y.reshape(fl, batch, pixels, c).permute(1, 0, 2, 3).contiguous()
+        recv = self.exchange(y.reshape(w, fl, batch, pp, c), "p2f_recv")
+        out = torch.empty((batch, fl, pixels, c), dtype=y.dtype, device=y.device)
+        return kernels.shard_pack(recv, out, batch, fl, pixels, w, pp, unpack=True)

@@ -34,10 +34,15 @@ class _PinnedUploads:
 
 
 class GraphedDenoiseStep:
-    def __init__(self, mv, scheduler, inputs, cameras, pano_latent, pers_latent, guidance, use_fps=True, warmup=2):
+    def __init__(self, mv, scheduler, inputs, cameras, pano_latent, pers_latent, guidance, use_fps=True, warmup=2, cfg_pair=None):
         """``inputs``: the keyword tensors of MultiViewBaseModel.forward (CFG-batched, resident on the GPU);
-        ``pano_latent`` [1,4,F,H,W] / ``pers_latent`` [1,m,4,F,h,w]: initial noisy latents."""
+        ``pano_latent`` [1,4,F,H,W] / ``pers_latent`` [1,m,4,F,h,w]: initial noisy latents.
+        Frame-sharded models (``mv.set_frame_shard``) capture their all-to-alls with the step: the exchange buffers are
+        pre-sized and cached (dist.FrameShard), RCCL collectives are stream operations.  ``cfg_pair``: process group of the
+        two ranks holding the two CFG halves of the same frames (dist.cfg_frame_layout) -- their predictions are exchanged
+        inside the captured step before the CFG combine."""
         self.mv, self.sch, self.inp, self.cams, self.g = mv, scheduler, inputs, cameras, float(guidance)
+        self.cfg_pair = cfg_pair
         dev = pano_latent.device
         # private copies: the caller's tensors may alias the model-input buffers the body writes into
         init_pano, init_pers = pano_latent.clone(), pers_latent.clone()
@@ -93,6 +98,9 @@ class GraphedDenoiseStep:
                 relative_position_tensor=inp["relative_position_tensor"], pitchs_tensor=inp["pitchs_tensor"])
         finally:
             self.mv.coins_preloaded = was
+        if self.cfg_pair is not None:
+            from .dist import exchange_cfg_halves
+            pred_pano, pred_pers = exchange_cfg_halves(pred_pano, self.cfg_pair), exchange_cfg_halves(pred_pers, self.cfg_pair)
         self.pred_pano, self.pred_pers = pred_pano, pred_pers          # static graph-pool tensors (inspection / tests)
         ldt = self.pano_lat.dtype            # latents may be kept in another 16-bit type than the model (the reference promotes)
         pred_pano, pred_pers = pred_pano.to(ldt), pred_pers.to(ldt)

@@ -20,6 +20,7 @@ _SIGNATURES = {
     "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR]),
     "im360_attn_fwd2": (_INT, [_PTR] * 6 + [_I64] * 19 + [_F32, _F32, _F32, _INT, _PTR]),
     "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
+    "im360_shard_pack": (_INT, [_PTR] * 2 + [_I64] * 6 + [_INT, _PTR]),
     "im360_gn_num_slabs": (_I64, [_I64] * 3),
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
     "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
@@ -192,22 +193,41 @@ def attention2(q, k, v, k2, v2, heads, scale=None, out_scale=1.0, out_scale2=1.0
     return out
 
 
-def temporal_attention(qkv, B, F, P, heads):
+def temporal_attention(qkv, B, F, P, heads, frame_major=False, out=None):
     """qkv [B*F*P, 3*C] = fused (q | k | v) projection of token-major activations [B, F, P, C].
-    Attention over the F axis per (batch, pixel, head).  Returns [B*F*P, C]."""
-    _dev(qkv)
+    Attention over the F axis per (batch, pixel, head).  Returns [B*F*P, C].
+    ``frame_major``: rows (and the result's) are ordered [F, B, P] instead -- the receive layout of the frame <-> pixel
+    all-to-all (``shard_pack``), read in place through the kernel's strides.  ``out``: preallocated result."""
+    _dev(qkv, out)
     C = qkv.shape[1] // 3
     assert qkv.shape[0] == B * F * P and qkv.stride(1) == 1
     rs = qkv.stride(0)
-    out = torch.empty((B * F * P, C), dtype=qkv.dtype, device=qkv.device)
+    if out is None:
+        out = torch.empty((B * F * P, C), dtype=qkv.dtype, device=qkv.device)
+    assert out.shape == (B * F * P, C) and out.is_contiguous() and out.dtype == qkv.dtype
     d = C // heads
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    fs, bs = (B * P, P) if frame_major else (P, F * P)          # frame / batch strides in rows
     rc = lib().im360_temporal_attn_fwd(_p(q), _p(k), _p(v), _p(out), B, F, P, heads, d,
-                                       P * rs, rs, F * P * rs, P * C, C, F * P * C,
+                                       fs * rs, rs, bs * rs, fs * C, C, bs * C,
                                        float(d ** -0.5), _dt(qkv), _stream())
     _check(rc, "im360_temporal_attn_fwd")
     _count("temporal", 4.0 * B * P * heads * F * F * d, qkv.element_size() * 4 * B * F * P * C)
     return out
+
+
+def shard_pack(src, dst, B, Fl, P, W, PP, unpack=False):
+    """Frame-sharded tokens [B, Fl, P, C] <-> the all-to-all buffer [W, Fl, B, PP, C] (``im360_shard_pack``); both tensors are
+    caller-owned (pre-sized, so the exchange can be graph-captured).  ``unpack``: buffer (src) -> tokens (dst)."""
+    _dev(src, dst)
+    C = src.shape[-1]
+    assert src.is_contiguous() and dst.is_contiguous() and dst.shape[-1] == C and src.dtype == dst.dtype and src.element_size() == 2
+    tok, buf = (dst, src) if unpack else (src, dst)
+    assert tok.numel() == B * Fl * P * C and buf.numel() == W * Fl * B * PP * C, (tok.shape, buf.shape)
+    rc = lib().im360_shard_pack(_p(src), _p(dst), B, Fl, P, C, W, PP, int(bool(unpack)), _stream())
+    _check(rc, "im360_shard_pack")
+    _count("misc", 0.0, 2 * tok.element_size() * tok.numel())
+    return dst
 
 
 # ------------------------------------------------------------------------------------------ group norm

@@ -119,25 +119,50 @@ class AnimationPipeline:
         return (pano.squeeze(2).permute(0, 2, 1, 3, 4).contiguous().to(latents_dtype),
                 pers.permute(0, 3, 2, 1, 4, 5).contiguous().to(latents_dtype))
 
-    def _encode_chunks(self, x, chunk=8):
+    def _encode_chunks(self, x, chunk=8, keep_rows=None):
+        """VAE-encode images [n, 3, H, W] in chunks of ``chunk`` and sample the posteriors (one randn per chunk, in order).
+        ``keep_rows`` (lo, hi): only the rows in [lo, hi) are needed (frame-sharded runs): chunks outside that range are
+        not encoded -- their posterior noise is still DRAWN (same shapes, same order) and dropped, so the kept rows get
+        exactly the samples of the unsharded run.  Returns the latents of all rows (keep_rows None) or of [lo, hi)."""
         self.vae.sample_on_host = self.rng == "host"
-        out = [self.vae.encode(x[i:i + chunk], x[i:i + chunk].shape[0]).latent_dist.sample() for i in range(0, x.shape[0], chunk)]
+        out = []
+        for i in range(0, x.shape[0], chunk):
+            xs = x[i:i + chunk]
+            n = xs.shape[0]
+            if keep_rows is not None and (i + n <= keep_rows[0] or i >= keep_rows[1]):
+                shape = (n, 4, xs.shape[-2] // 8, xs.shape[-1] // 8)
+                if self.vae.sample_on_host:
+                    torch.randn(shape, dtype=torch.float32)
+                else:
+                    torch.randn(shape, device=x.device)
+                continue
+            lat = self.vae.encode(xs, n).latent_dist.sample()
+            if keep_rows is not None:
+                lat = lat[max(keep_rows[0] - i, 0):max(min(keep_rows[1] - i, n), 0)]
+            out.append(lat)
         return torch.cat(out)
 
-    def prepare_masked_latents_pano(self, video_length, pix_masked, pano_mask):
-        """(:427-448) pix [b f c h w] -> latents [b c f h w]; mask nearest-resized to latent resolution."""
+    def prepare_masked_latents_pano(self, video_length, pix_masked, pano_mask, keep=None):
+        """(:427-448) pix [b f c h w] -> latents [b c f h w]; mask nearest-resized to latent resolution.
+        ``keep`` (first frame, count): encode only these frames (b == 1); the mask is returned for all frames."""
         b = pix_masked.shape[0]
-        lat = self._encode_chunks(pix_masked.reshape(b * video_length, *pix_masked.shape[2:]))
-        lat = lat.reshape(b, video_length, *lat.shape[1:]).permute(0, 2, 1, 3, 4) * VAE_SCALE
+        rows = None if keep is None else (keep[0], keep[0] + keep[1])
+        fl = video_length if keep is None else keep[1]
+        assert keep is None or b == 1
+        lat = self._encode_chunks(pix_masked.reshape(b * video_length, *pix_masked.shape[2:]), keep_rows=rows)
+        lat = lat.reshape(b, fl, *lat.shape[1:]).permute(0, 2, 1, 3, 4) * VAE_SCALE
         mask = pano_mask.transpose(2, 1)
         mask = F.interpolate(mask, size=(mask.shape[2], lat.shape[-2], lat.shape[-1]))
         return lat, mask.to(lat.device)
 
-    def prepare_masked_latents_pers(self, video_length, pix_masked, pers_masks):
-        """(:451-473) pix [b f m c h w] -> latents [b m c f h w]."""
+    def prepare_masked_latents_pers(self, video_length, pix_masked, pers_masks, keep=None):
+        """(:451-473) pix [b f m c h w] -> latents [b m c f h w]; ``keep`` as in ``prepare_masked_latents_pano``."""
         b, _, m = pix_masked.shape[:3]
-        lat = self._encode_chunks(pix_masked.reshape(b * video_length * m, *pix_masked.shape[3:]))
-        lat = lat.reshape(b, video_length, m, *lat.shape[1:]).permute(0, 2, 3, 1, 4, 5) * VAE_SCALE
+        rows = None if keep is None else (keep[0] * m, (keep[0] + keep[1]) * m)
+        fl = video_length if keep is None else keep[1]
+        assert keep is None or b == 1
+        lat = self._encode_chunks(pix_masked.reshape(b * video_length * m, *pix_masked.shape[3:]), keep_rows=rows)
+        lat = lat.reshape(b, fl, m, *lat.shape[1:]).permute(0, 2, 3, 1, 4, 5) * VAE_SCALE
         mk = pers_masks.permute(0, 3, 1, 2, 4, 5).squeeze(0)
         mk = F.interpolate(mk, size=(m, lat.shape[-2], lat.shape[-1])).unsqueeze(3)
         return lat, mk.permute(0, 2, 3, 1, 4, 5).to(lat.device)
@@ -192,78 +217,84 @@ class AnimationPipeline:
         pano_latent, pers_latent = self.init_noise(1, f, H // 8, W // 8, ps // 8, ps // 8, cameras, device, latents_dtype)
         sh = frame_shard
         if sh is not None:
-            # every rank drew the whole clip's noise from the same seed (and below encodes all frames, so the VAE
-            # posterior samples are the unsharded run's): cut to the local frames
+            # every rank drew the whole clip's noise from the same seed: cut to the local frames
             pano_latent, pers_latent = sh.take(pano_latent, 2).contiguous(), sh.take(pers_latent, 3).contiguous()
-        pano_ml, pano_mask_l = self.prepare_masked_latents_pano(f, pano_pix_masked, pano_mask.to(device))
-        pers_ml, pers_mask_l = self.prepare_masked_latents_pers(f, pers_pix_masked, pers_masks.to(device))
+        # frame-sharded: only this rank's frames go through the VAE encoder; the posterior noise of the other frames is still
+        # drawn (and dropped), so the samples are those of the unsharded run
+        keep = None if sh is None else (sh.f0, sh.local)
+        pano_ml, pano_mask_l = self.prepare_masked_latents_pano(f, pano_pix_masked, pano_mask.to(device), keep)
+        pers_ml, pers_mask_l = self.prepare_masked_latents_pers(f, pers_pix_masked, pers_masks.to(device), keep)
         if sh is not None:
-            pano_ml, pano_mask_l = sh.take(pano_ml, 2), sh.take(pano_mask_l, 2)
-            pers_ml, pers_mask_l = sh.take(pers_ml, 3), sh.take(pers_mask_l, 3)
+            pano_mask_l, pers_mask_l = sh.take(pano_mask_l, 2), sh.take(pers_mask_l, 3)
             self.mv_base_model.set_frame_shard(sh)
+        try:
+            if prompt_embeds is not None:
+                text_pano, text_pers = prompt_embeds
+            else:
+                text_pano = self._encode_prompt([prompt], device, num_videos_per_prompt, cfg, [negative_prompt])
+                text_pers = text_pano.repeat_interleave(m, dim=0)     # the reference encodes the same prompt m times (:628, :655)
+            text_pano, text_pers = text_pano.to(device, latents_dtype), text_pers.to(device, latents_dtype)
+            if sam_features is not None:
+                sam_pano, sam_pers = sam_features
+            else:
+                sam_pano = self._sam_features(vb["anchor_pixels_values"].to(device))
+                sam_pers = self._sam_features(vb["anchor_pixels_values_pers"].to(device))
+            feat_pano = torch.cat([sam_pano, sam_pano]).to(device, latents_dtype)
+            feat_pers = torch.cat([sam_pers, sam_pers]).to(device, latents_dtype).unsqueeze(1).expand(-1, m, -1, -1, -1)
+            fps = torch.tensor(vb["fps"], device=device).unsqueeze(0)
+            fps_pano = torch.cat([fps] * 2) if use_fps_condition else None
+            fps_pers = torch.cat([fps.unsqueeze(-1).repeat(1, m)] * 2) if use_fps_condition else None
+            rel = torch.cat([vb["relative_position"].to(device).unsqueeze(0)] * 2)
+            pitch = torch.cat([vb["pitchs"].to(device).unsqueeze(0)] * 2)
+            ts_dev = [torch.tensor([t], dtype=torch.int64, device=device) for t in steps_host]
+            dt = latents_dtype
+            # static halves of the model input: mask + masked latent (channels 4..8), duplicated for CFG
+            in_pano = torch.cat([torch.cat((pano_latent, pano_mask_l.to(dt), pano_ml.to(dt)), dim=1)] * 2)
+            in_pers = torch.cat([torch.cat((pers_latent, pers_mask_l.to(dt), pers_ml.to(dt)), dim=2)] * 2)
 
-        if prompt_embeds is not None:
-            text_pano, text_pers = prompt_embeds
-        else:
-            text_pano = self._encode_prompt([prompt], device, num_videos_per_prompt, cfg, [negative_prompt])
-            text_pers = text_pano.repeat_interleave(m, dim=0)     # the reference encodes the same prompt m times (:628, :655)
-        text_pano, text_pers = text_pano.to(device, latents_dtype), text_pers.to(device, latents_dtype)
-        if sam_features is not None:
-            sam_pano, sam_pers = sam_features
-        else:
-            sam_pano = self._sam_features(vb["anchor_pixels_values"].to(device))
-            sam_pers = self._sam_features(vb["anchor_pixels_values_pers"].to(device))
-        feat_pano = torch.cat([sam_pano, sam_pano]).to(device, latents_dtype)
-        feat_pers = torch.cat([sam_pers, sam_pers]).to(device, latents_dtype).unsqueeze(1).expand(-1, m, -1, -1, -1)
-        fps = torch.tensor(vb["fps"], device=device).unsqueeze(0)
-        fps_pano = torch.cat([fps] * 2) if use_fps_condition else None
-        fps_pers = torch.cat([fps.unsqueeze(-1).repeat(1, m)] * 2) if use_fps_condition else None
-        rel = torch.cat([vb["relative_position"].to(device).unsqueeze(0)] * 2)
-        pitch = torch.cat([vb["pitchs"].to(device).unsqueeze(0)] * 2)
-        ts_dev = [torch.tensor([t], dtype=torch.int64, device=device) for t in steps_host]
-        dt = latents_dtype
-        # static halves of the model input: mask + masked latent (channels 4..8), duplicated for CFG
-        in_pano = torch.cat([torch.cat((pano_latent, pano_mask_l.to(dt), pano_ml.to(dt)), dim=1)] * 2)
-        in_pers = torch.cat([torch.cat((pers_latent, pers_mask_l.to(dt), pers_ml.to(dt)), dim=2)] * 2)
+            graphed = None
+            import torch.distributed as tdist
+            capturable = sh is None or (tdist.is_initialized() and tdist.get_backend(sh.group) == "nccl")     # RCCL all-to-alls are stream ops
+            if self.use_graph and self.rng == "device" and pano_latent.is_cuda and trace is None and callback is None and capturable:
+                from .graph_step import GraphedDenoiseStep
+                inputs = dict(latents=in_pers, pano_latent=in_pano, prompt_embd=text_pers, pano_prompt_embd=text_pano,
+                              fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers, reference_images_clip_feat_pano=feat_pano,
+                              reference_images_clip_feat_pers=feat_pers, relative_position_tensor=rel, pitchs_tensor=pitch)
+                graphed = GraphedDenoiseStep(self.mv_base_model, self.scheduler, inputs, cameras, pano_latent, pers_latent,
+                                             guidance_scale_text, use_fps=use_fps_condition, warmup=1)       # one eager step fills every cache
+            for i, t in enumerate(self.progress_bar(steps_host)):
+                if graphed is not None:
+                    pano_latent, pers_latent = graphed.step(t)
+                    continue
+                in_pano[:, :4] = pano_latent
+                in_pers[:, :, :4] = pers_latent
+                pred_pers, pred_pano = self.mv_base_model(
+                    latents=in_pers, pano_latent=in_pano, timestep=ts_dev[i], prompt_embd=text_pers,
+                    pano_prompt_embd=text_pano, cameras=cameras, use_fps_condition=use_fps_condition,
+                    use_ip_plus_cross_attention=use_ip_plus_cross_attention, fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers,
+                    reference_images_clip_feat_pano=feat_pano, reference_images_clip_feat_pers=feat_pers,
+                    relative_position_tensor=rel, pitchs_tensor=pitch)
+                pano_latent = self._cfg_step(pred_pano, guidance_scale_text, t, pano_latent)
+                pers_latent = self._cfg_step(pred_pers, guidance_scale_text, t, pers_latent)
+                if trace is not None:
+                    trace.append(pano_latent.clone())
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, pano_latent)
 
-        graphed = None
-        if self.use_graph and self.rng == "device" and pano_latent.is_cuda and trace is None and callback is None and sh is None:
-            from .graph_step import GraphedDenoiseStep
-            inputs = dict(latents=in_pers, pano_latent=in_pano, prompt_embd=text_pers, pano_prompt_embd=text_pano,
-                          fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers, reference_images_clip_feat_pano=feat_pano,
-                          reference_images_clip_feat_pers=feat_pers, relative_position_tensor=rel, pitchs_tensor=pitch)
-            graphed = GraphedDenoiseStep(self.mv_base_model, self.scheduler, inputs, cameras, pano_latent, pers_latent,
-                                         guidance_scale_text, use_fps=use_fps_condition, warmup=1)       # one eager step fills every cache
-        for i, t in enumerate(self.progress_bar(steps_host)):
-            if graphed is not None:
-                pano_latent, pers_latent = graphed.step(t)
-                continue
-            in_pano[:, :4] = pano_latent
-            in_pers[:, :, :4] = pers_latent
-            pred_pers, pred_pano = self.mv_base_model(
-                latents=in_pers, pano_latent=in_pano, timestep=ts_dev[i], prompt_embd=text_pers,
-                pano_prompt_embd=text_pano, cameras=cameras, use_fps_condition=use_fps_condition,
-                use_ip_plus_cross_attention=use_ip_plus_cross_attention, fps_tensor_pano=fps_pano, fps_tensor_pers=fps_pers,
-                reference_images_clip_feat_pano=feat_pano, reference_images_clip_feat_pers=feat_pers,
-                relative_position_tensor=rel, pitchs_tensor=pitch)
-            pano_latent = self._cfg_step(pred_pano, guidance_scale_text, t, pano_latent)
-            pers_latent = self._cfg_step(pred_pers, guidance_scale_text, t, pers_latent)
-            if trace is not None:
-                trace.append(pano_latent.clone())
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, pano_latent)
-
-        video = self.decode_latents(self.padding_pano(pano_latent, latent=True))
-        video = self.unpadding_pano(video)
-        if sh is not None:                  # latent / video boundary: the only collective besides the motion-module exchanges
-            self.mv_base_model.set_frame_shard(None)
-            video = sh.gather_frames(torch.from_numpy(np.ascontiguousarray(video)).to(device), 2).cpu().numpy()
-            pano_latent = sh.gather_frames(pano_latent, 2)
-            pers_latent = sh.gather_frames(pers_latent, 3)
-        if output_type == "tensor":
-            video = torch.from_numpy(np.ascontiguousarray(video))
-        self.last_latents = (pano_latent, pers_latent)
-        return AnimationPipelineOutput(videos=video) if return_dict else video
+            video = self.decode_latents(self.padding_pano(pano_latent, latent=True))
+            video = self.unpadding_pano(video)
+            if sh is not None:                  # latent / video boundary: the only collective besides the motion-module exchanges
+                self.mv_base_model.set_frame_shard(None)
+                video = sh.gather_frames(torch.from_numpy(np.ascontiguousarray(video)).to(device), 2).cpu().numpy()
+                pano_latent = sh.gather_frames(pano_latent, 2)
+                pers_latent = sh.gather_frames(pers_latent, 3)
+            if output_type == "tensor":
+                video = torch.from_numpy(np.ascontiguousarray(video))
+            self.last_latents = (pano_latent, pers_latent)
+            return AnimationPipelineOutput(videos=video) if return_dict else video
+        finally:
+            if sh is not None:
+                self.mv_base_model.set_frame_shard(None)      # also when the loop raises: the model must not stay sharded
 
     def _cfg_step(self, pred, g, t, latent):
         u, c = pred.to(latent.dtype).chunk(2)          # latents_dtype may differ from the model dtype (the reference promotes)

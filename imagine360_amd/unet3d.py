@@ -299,11 +299,13 @@ class VersatileAttention(QKVAttention):
         if sh is None:
             a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads)
         else:
-            # frame-sharded -> pixel-sharded (one all-to-all over xGMI), full-length attention, and back
+            # frame-sharded -> pixel-sharded (one all-to-all over xGMI; pack = one kernel), attention over ALL frames reading
+            # the receive buffer in place and writing the return trip's send buffer, and back (all-to-all + one unpack kernel)
             q = sh.frames_to_pixels(qkv.reshape(batch, frames, pixels, 3 * c))
-            pp = q.shape[2]
-            a = kernels.temporal_attention(q.reshape(-1, 3 * c), batch, sh.total, pp, self.heads)
-            a = sh.pixels_to_frames(a.reshape(batch, sh.total, pp, c), pixels).reshape(-1, c)
+            pp = sh.pixels_per_rank(pixels)
+            a = kernels.temporal_attention(q, batch, sh.total, pp, self.heads, frame_major=True,
+                                           out=sh.pixel_result_buffer(qkv, batch, pixels, c))
+            a = sh.pixels_to_frames(a, batch, pixels).reshape(-1, c)
         return self.out_proj(a, residual, row_stats=row_stats)
 
 

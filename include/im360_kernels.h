@@ -66,6 +66,15 @@ int im360_temporal_attn_fwd(const void* q, const void* k, const void* v, void* o
                             int64_t o_fs, int64_t o_ps, int64_t o_bs,
                             float scale, int dtype, void* stream);
 
+/* Frame-chunk sharding (one process per GPU, imagine360_amd.dist.FrameShard): frame-sharded tokens [B, Fl, P, C] (16-bit,
+ * C % 8 == 0) <-> the buffer of the frame <-> pixel all-to-all, [W][Fl][B][PP][C] (W ranks, PP = ceil(P / W), the tail of
+ * the last rank zero-filled); dir 0 packs, 1 unpacks.  The receive side of the exchange is read IN PLACE by
+ * im360_temporal_attn_fwd through its frame / batch / pixel strides (frame stride B * PP * C), which also writes the
+ * return trip's send buffer directly.  Pre-sized caller-owned buffers: the exchange can be captured in a hipGraph.
+ * Replaces: nothing in the reference (single process); it surrounds VersatileAttention, motion_module.py:343-429. */
+int im360_shard_pack(const void* src, void* dst, int64_t B, int64_t Fl, int64_t P, int64_t C, int64_t W, int64_t PP,
+                     int dir, void* stream);
+
 /* GroupNorm statistics -> per-(image, channel) fp32 scale/shift such that GN(x) = x*scale + shift.
  * pad > 0: statistics of the circularly W-padded tensor (the pano branch pads before norm1,
  * src/models/MVGenModel.py:277-278).  partial: fp32 workspace of N * S * 2 * C floats,

@@ -45,11 +45,27 @@ def attention2(q, k, v, k2, v2, heads, scale=None, out_scale=1.0, out_scale2=1.0
     return (a + b).to(q.dtype)
 
 
-def temporal_attention(qkv, B, Fr, P, heads):
+def temporal_attention(qkv, B, Fr, P, heads, frame_major=False, out=None):
     C = qkv.shape[1] // 3
-    t = qkv.reshape(B, Fr, P, 3 * C).permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
-    o = attention(t[..., :C], t[..., C:2 * C], t[..., 2 * C:], heads)
-    return o.reshape(B, P, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr * P, C).contiguous()
+    x = qkv.reshape(Fr, B, P, 3 * C).permute(1, 0, 2, 3) if frame_major else qkv.reshape(B, Fr, P, 3 * C)
+    t = x.permute(0, 2, 1, 3).reshape(B * P, Fr, 3 * C)
+    o = attention(t[..., :C], t[..., C:2 * C], t[..., 2 * C:], heads).reshape(B, P, Fr, C)
+    o = (o.permute(2, 0, 1, 3) if frame_major else o.permute(0, 2, 1, 3)).reshape(B * Fr * P, C).contiguous()
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def shard_pack(src, dst, B, Fl, P, W, PP, unpack=False):
+    C = src.shape[-1]
+    if unpack:
+        t = src.reshape(W, Fl, B, PP, C).permute(2, 1, 0, 3, 4).reshape(B, Fl, W * PP, C)[:, :, :P]
+        dst.copy_(t.reshape(dst.shape))
+    else:
+        t = F.pad(src.reshape(B, Fl, P, C), (0, 0, 0, W * PP - P)).reshape(B, Fl, W, PP, C).permute(2, 1, 0, 3, 4)
+        dst.copy_(t.reshape(dst.shape))
+    return dst
 
 
 def _pad_w(x_nchw, pad):
@@ -244,7 +260,7 @@ def linear_geglu(x, w, b, inner):
 
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
           "conv2d", "pack_conv_up2_weight", "conv_up2", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2", "pack_attn_bias",
-          "conv1x1_cat", "linear", "linear_ln", "linear_geglu_ln", "interleave_geglu"]
+          "conv1x1_cat", "linear", "linear_ln", "linear_geglu_ln", "interleave_geglu", "shard_pack"]
 
 
 @contextlib.contextmanager

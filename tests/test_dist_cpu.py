@@ -62,19 +62,23 @@ def test_sample_parallel_latent_gather():
 
 
 def _exchange_job(rank, world):
+    import _emu_kernels as E
     from imagine360_amd.dist import FrameShard
     b, f, p, c = 2, 6, 7, 8                      # 7 pixels: exercises the zero-padded last pixel shard
     full = torch.arange(b * f * p * c, dtype=torch.float32).reshape(b, f, p, c)
     sh = FrameShard(f)
     loc = sh.take(full, 1).contiguous()
-    px = sh.frames_to_pixels(loc)                # [b, f, ceil(p/world), c]
-    pp = px.shape[2]
-    lo = rank * pp
-    want = torch.zeros(b, f, pp, c)
-    n = max(0, min(p, lo + pp) - lo)
-    want[:, :, :n] = full[:, :, lo:lo + n]
-    ok1 = torch.equal(px, want)
-    back = sh.pixels_to_frames(px, p)
+    with E.patched_kernels():
+        pp = sh.pixels_per_rank(p)
+        px = sh.frames_to_pixels(loc).reshape(f, b, pp, c)          # rows (frame, batch, pixel): this rank's pixels of ALL frames
+        lo = rank * pp
+        want = torch.zeros(b, f, pp, c)
+        n = max(0, min(p, lo + pp) - lo)
+        want[:, :, :n] = full[:, :, lo:lo + n]
+        ok1 = torch.equal(px.permute(1, 0, 2, 3), want)
+        buf = sh.pixel_result_buffer(loc, b, p, c)                  # the return trip's send buffer, same row order
+        buf.copy_(px.reshape(-1, c))
+        back = sh.pixels_to_frames(buf, b, p)
     ok2 = torch.equal(back, loc)
     ok3 = torch.equal(sh.gather_frames(loc, 1), full)
     return bool(ok1 and ok2 and ok3)
@@ -186,3 +190,57 @@ def test_cfg_halves_on_two_rank_groups_match_the_cfg_batched_forward():
     for r in range(2):
         assert out[r][0] < 1e-5 and out[r][1] < 1e-5, out[r]
         assert out[r][2] == [1, 4, 2, 32, 64]
+
+
+def _pipeline_sharded_job(rank, world):
+    """The whole pipeline call (noise, masked-latent VAE encode of the LOCAL frames only, 2 DDIM steps with the motion
+    modules' all-to-alls, decode, frame gather) frame-sharded over 2 ranks == the unsharded call from the same seeds; and a
+    call that raises inside the loop leaves the model unsharded."""
+    import random
+    import _emu_kernels as E
+    from imagine360_amd import configs, synthetic as S
+    from imagine360_amd.dist import FrameShard
+    from imagine360_amd.pipeline import AnimationPipeline
+    from imagine360_amd.scheduler import DDIMScheduler
+    from imagine360_amd.unet3d import VersatileAttention
+    mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True, motion_heads=4)
+    vae = configs.build_vae(4, device="cpu", dtype=torch.float32)
+    pipe = AnimationPipeline(vae, None, None, mv.unet, mv.pano_unet, mv, DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS), None, "SAM")
+    pipe.rng, pipe._no_progress, pipe.use_graph = "host", True, False
+    frames = 4
+    vb = S.video_batch(frames=frames, pano_hw=(128, 256), seed=3)
+    cond = S.conditioning(frames=16, seed=3)
+    kw = dict(num_inference_steps=2, guidance_scale_text=7.5, negative_prompt="", latents_dtype=torch.float32, video_batch=vb,
+              use_outpaint=True, use_ip_plus_cross_attention=True, use_fps_condition=True, ip_plus_condition="video",
+              prompt_embeds=(cond["text_pano"], cond["text_pers"]), sam_features=(cond["sam_pano"], cond["sam_pers"]))
+    with E.patched_kernels():
+        torch.manual_seed(9)
+        random.seed(9)
+        full = pipe("synthetic", **kw).videos
+        full_lat = pipe.last_latents[0].clone()
+        encoded = []
+        orig = vae.encode
+        vae.encode = lambda x, *a, **k: (encoded.append(x.shape[0]), orig(x, *a, **k))[1]
+        torch.manual_seed(9)
+        random.seed(9)
+        sh = FrameShard(frames)
+        part = pipe("synthetic", frame_shard=sh, **kw).videos
+        vae.encode = orig
+        part_lat = pipe.last_latents[0]
+        unsharded_after = all(m.frame_shard is None for m in mv.modules() if isinstance(m, VersatileAttention))
+        raised = False
+        try:
+            pipe("synthetic", frame_shard=sh, **dict(kw, callback=lambda *a: 1 / 0))
+        except ZeroDivisionError:
+            raised = True
+        clean_after_error = all(m.frame_shard is None for m in mv.modules() if isinstance(m, VersatileAttention))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    return [rel(part, full), rel(part_lat, full_lat), sum(encoded), unsharded_after, raised and clean_after_error]
+
+
+def test_frame_sharded_pipeline_call_matches_unsharded():
+    out = _run(_pipeline_sharded_job)
+    for r in range(2):
+        assert out[r][0] < 1e-5 and out[r][1] < 1e-5, out[r]
+        assert out[r][2] == 4 + 4 * 20 // 2, out[r]         # images through the VAE encoder: one 8-image chunk holds all 4 panorama frames; half of the 80 views
+        assert out[r][3] and out[r][4], out[r]

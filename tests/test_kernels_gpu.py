@@ -157,9 +157,9 @@ def test_attention_packed_bias_through_the_matrix_pipe(dt, B, H, Nq, Nk):
             out = K.attention(dq, dk, dv, H, bias=pb, bias_packed=True)
             assert rel(out, ref) < TOL[dt] and blockrel(out, ref, 32) < 2 * TOL[dt], qb
             assert rel(out, K.attention(dq, dk, dv, H, bias=db).float().cpu()) < TOL[dt]
-            if qb == 2:      # default: the wave's mask rows fetched coalesced and passed through its LDS patch; knob attn_hl = 1:
-                try:         # fragments straight from global memory -- the same arithmetic, so the same bits
-                    K.tuning_set("attn_hl", 1)
+            if qb == 2:      # knob attn_hl = 2: the wave's mask rows fetched coalesced and passed through its LDS patch instead of
+                try:         # per-lane fragments straight from global memory -- the same arithmetic, so the same bits
+                    K.tuning_set("attn_hl", 2)
                     assert torch.equal(K.attention(dq, dk, dv, H, bias=pb, bias_packed=True), out)
                 finally:
                     K.tuning_set("attn_hl", 0)

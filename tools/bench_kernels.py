@@ -69,9 +69,9 @@ def bench_attn_variants(iters):
             t = timeit(lambda: K.attention(q, k, v, H, bias=pbb, bias_packed=True), iters)
             row.append(f"packed bias QB={qb}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
         K.tuning_set("attn_qb", 2)
-        K.tuning_set("attn_hl", 1)          # A/B: mask fragments straight from global memory (round 2) vs through the wave's LDS patch
+        K.tuning_set("attn_hl", 2)          # A/B: mask rows through the wave's LDS patch instead of per-lane fragments from global memory
         t = timeit(lambda: K.attention(q, k, v, H, bias=pbb, bias_packed=True), iters)
-        row.append(f"packed QB=2, fragments from global memory: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
+        row.append(f"packed QB=2, mask rows through LDS: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s")
         K.tuning_set("attn_hl", 0)
         K.tuning_set("attn_qb", 0)
         print(f"attn  {name:14s} " + " | ".join(row))
