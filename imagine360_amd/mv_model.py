@@ -35,10 +35,12 @@ class SphericalPE(nn.Module):
     def forward(self, coords):
         shape = coords.shape[:-1]
         base = 2 if self.N_freqs <= 80 else 5000 ** (1 / (self.N_freqs / 2.5))
-        freq = base ** torch.linspace(0, self.N_freqs - 1, self.N_freqs, device=coords.device)   # fp32, not the (castable) buffer
-        # evaluated on the host: sin/cos of arguments up to 2^79 * pi only reproduce the CPU reference when
-        # the same libm is used; this runs once per resolution (WarpAttn caches the result)
-        freq = freq.cpu()
+        # fp32 and built ON THE HOST like the reference's buffer (transformer.py:184-188, at module construction), not from
+        # the (castable) buffer and not on the device: the GPU's pow() is not exact for 2^31 ... 2^63, and a one-ulp
+        # frequency turns sin / cos of such arguments into different numbers (measured: 50 % relative difference of the
+        # table at 128 / 256 channels, 5e-3 on the panorama prediction).  sin / cos are evaluated on the host too -- arguments
+        # up to 2^79 * pi only reproduce the CPU reference with the same libm; once per resolution (WarpAttn caches it)
+        freq = base ** torch.linspace(0, self.N_freqs - 1, self.N_freqs)
         enc = coords.float().cpu().reshape(-1, 2, 1) * freq
         return torch.cat([enc.sin(), enc.cos()], dim=1).reshape(*shape, -1).to(coords.device)
 

@@ -78,7 +78,7 @@ def _mv_job(rank, world):
     import random
     from imagine360_amd import configs, synthetic as S
     from imagine360_amd.dist import FrameShard, shard_mv_inputs
-    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    dt, dev = torch.float16, torch.device("cuda", 0)
     mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True)
     mv.noise_on_host = True
     frames = 8
@@ -103,9 +103,12 @@ def _mv_job(rank, world):
 
 
 def test_frame_sharded_mv_forward_on_the_kernels_matches_unsharded():
-    """Same kernels on the same per-frame data: the only arithmetic that can differ is hipBLASLt choosing another solution
-    for the halved token counts of the small Linears, so the two runs agree far below the 16-bit storage error (1.7e-2)."""
+    """Same kernels on the same per-frame data in fp16: the only arithmetic that can differ is hipBLASLt choosing another
+    solution for the halved token counts of the small Linears -- last-bit differences that the ~60 layers decorrelate up
+    to the storage error of the format (2.1e-3 for one run against fp32, ~3e-3 between two runs); a frame, pixel shard or
+    head in the wrong place is an O(1) error."""
     out = _run(_mv_job)
+    print("sharded vs unsharded (pano, pers, gathered pano):", {r: out[r][:3] for r in out})
     for r in range(2):
         assert out[r][4] and out[r][3] == [2, 4, 4, 32, 64], out[r]
-        assert out[r][0] < 5e-3 and out[r][1] < 5e-3 and out[r][2] < 5e-3, out[r]
+        assert out[r][0] < 6e-3 and out[r][1] < 6e-3 and out[r][2] < 6e-3, out[r]
