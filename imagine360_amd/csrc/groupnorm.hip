@@ -180,6 +180,184 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- all three passes in ONE launch -------------------------------------------------------------------------------
+// Workgroup (image n, slab s): (1) the slab's per-channel partial sums -> partial[n][s] (exactly gn_partial_kernel's), a
+// release fence and one atomic increment of counter[n]; (2) wait until all S slabs of the image have arrived, then every
+// workgroup reduces the image's partials itself, in gn_finalize_kernel's fixed order and in fp64 (so scale / shift are
+// bit-identical to the three-kernel path), into LDS; (3) act(x * scale + shift) on its slab of the output.  The second
+// read of the slab comes out of the L2 / Infinity Cache a few microseconds after the first instead of from HBM one
+// whole-tensor pass later: 2 HBM passes instead of 3, one launch instead of three.  Liveness: workgroups are dispatched in
+// block-id order (image-major), so a waiting workgroup only ever waits for ids that are resident or will be as soon as
+// an EARLIER image finishes; nothing waits on a later image.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ xa, const T* __restrict__ xb, int C1, int C2,
+                                                        float* __restrict__ partial, int* __restrict__ counter,
+                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                        T* __restrict__ y, int H, int W, int G, int pad, int act, int S,
+                                                        float eps, int cmax) {
+    __shared__ float red[256 * 16];
+    extern __shared__ float sc_sh[];                 // [2][C]: scale | shift of image n
+    const int n = blockIdx.x / S, s = blockIdx.x % S, tid = threadIdx.x;
+    const int HW = H * W, C = C1 + C2;
+    // ---- (1) partial sums of this slab, both sources
+    {
+        const int pps = (HW + S - 1) / S;
+        const int pix0 = s * pps, pix1 = min(HW, pix0 + pps);
+        for (int src = 0; src < (xb ? 2 : 1); ++src) {
+            const T* x = src ? xb : xa;
+            const int Cx = src ? C2 : C1, coff = src ? C1 : 0;
+            const int nch = Cx >> 3;
+            const T* xbase = x + (long)n * HW * Cx;
+            for (int c0 = 0; c0 < nch; c0 += 256) {
+                const int ncp = min(256, nch - c0);
+                const int lanes = 256 / ncp;
+                const int cc = tid % ncp, pl = tid / ncp;
+                float acc[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                if (pl < lanes) {
+                    const T* xc = xbase + (c0 + cc) * 8;
+                    auto add = [&](const uint4& raw, int pix) {
+                        float f[8];
+                        unpack8<T>(raw, f);
+                        float wgt = 1.f;
+                        if (pad > 0) {
+                            const int xx = pix % W;
+                            if (xx < pad || xx >= W - pad) wgt = 2.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            acc[e] += wgt * f[e];
+                            acc[8 + e] += wgt * f[e] * f[e];
+                        }
+                    };
+                    int pix = pix0 + pl;
+                    for (; pix + 3 * lanes < pix1; pix += 4 * lanes) {
+                        const uint4 r0 = *(const uint4*)(xc + (long)pix * Cx);
+                        const uint4 r1 = *(const uint4*)(xc + (long)(pix + lanes) * Cx);
+                        const uint4 r2 = *(const uint4*)(xc + (long)(pix + 2 * lanes) * Cx);
+                        const uint4 r3 = *(const uint4*)(xc + (long)(pix + 3 * lanes) * Cx);
+                        add(r0, pix);
+                        add(r1, pix + lanes);
+                        add(r2, pix + 2 * lanes);
+                        add(r3, pix + 3 * lanes);
+                    }
+                    for (; pix < pix1; pix += lanes) add(*(const uint4*)(xc + (long)pix * Cx), pix);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[tid * 16 + e] = acc[e];
+                __syncthreads();
+                if (pl == 0) {
+                    for (int l = 1; l < lanes; ++l)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[e] += red[(l * ncp + cc) * 16 + e];
+                    float* dst = partial + ((long)(n * S + s) * 2) * C + coff + (c0 + cc) * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        dst[e] = acc[e];
+                        dst[C + e] = acc[8 + e];
+                    }
+                }
+            }
+        }
+    }
+    // ---- arrive, wait for the image's other slabs
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(counter + n, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter + n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // ---- (2) scale / shift of every channel of image n: one wave per group at a time, gn_finalize_kernel's order
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int cpg = C / G;
+        const double count = (double)H * (double)(W + 2 * pad) * (double)cpg;
+        for (int g = wave; g < G; g += 4) {
+            double sum = 0.0, sq = 0.0;
+            const float* base = partial + (long)n * S * 2 * C + g * cpg;
+            for (int i = lane; i < S * cpg; i += 64) {
+                const int sl = i / cpg, j = i % cpg;
+                const float* src = base + (long)sl * 2 * C + j;
+                sum += (double)__builtin_nontemporal_load(src);
+                sq += (double)__builtin_nontemporal_load(src + C);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sum += __shfl_xor(sum, o);
+                sq += __shfl_xor(sq, o);
+            }
+            const double mean = sum / count;
+            double var = sq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            for (int j = lane; j < cpg; j += 64) {
+                const int c = g * cpg + j;
+                const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
+                sc_sh[c] = (float)(rstd * ga);
+                sc_sh[cmax + c] = (float)(be - mean * rstd * ga);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- (3) apply on this workgroup's slab of the (W + 2 pad wide) output, both sources
+    {
+        const int Wo = W + 2 * pad, HWo = H * Wo;
+        const int pps = (HWo + S - 1) / S;
+        const int pix0 = s * pps, pix1 = min(HWo, pix0 + pps);
+        T* yb = y + (long)n * HWo * C;
+        for (int src = 0; src < (xb ? 2 : 1); ++src) {
+            const T* x = src ? xb : xa;
+            const int Cx = src ? C2 : C1, coff = src ? C1 : 0;
+            const int nch = Cx >> 3;
+            const T* xbase = x + (long)n * HW * Cx;
+            for (int c0 = 0; c0 < nch; c0 += 256) {
+                const int ncp = min(256, nch - c0);
+                const int lanes = 256 / ncp;
+                const int cc = tid % ncp, pl = tid / ncp;
+                if (pl >= lanes) continue;
+                float sc[8], sh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sc[e] = sc_sh[coff + (c0 + cc) * 8 + e];
+                    sh[e] = sc_sh[cmax + coff + (c0 + cc) * 8 + e];
+                }
+                const T* xc = xbase + (c0 + cc) * 8;
+                T* yc = yb + coff + (c0 + cc) * 8;
+                auto srcp = [&](int pix) {
+                    int sx = pix % Wo - pad;
+                    const int sy = pix / Wo;
+                    if (sx < 0) sx += W;
+                    else if (sx >= W) sx -= W;
+                    return *(const uint4*)(xc + ((long)sy * W + sx) * Cx);
+                };
+                auto emit = [&](const uint4& raw, int pix) {
+                    float f[8];
+                    unpack8<T>(raw, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v = f[e] * sc[e] + sh[e];
+                        f[e] = act ? silu_f(v) : v;
+                    }
+                    *(uint4*)(yc + (long)pix * C) = pack8<T>(f);
+                };
+                int pix = pix0 + pl;
+                for (; pix + 3 * lanes < pix1; pix += 4 * lanes) {
+                    const uint4 r0 = srcp(pix), r1 = srcp(pix + lanes), r2 = srcp(pix + 2 * lanes), r3 = srcp(pix + 3 * lanes);
+                    emit(r0, pix);
+                    emit(r1, pix + lanes);
+                    emit(r2, pix + 2 * lanes);
+                    emit(r3, pix + 3 * lanes);
+                }
+                for (; pix < pix1; pix += lanes) emit(srcp(pix), pix);
+            }
+        }
+    }
+}
+
 // ---- circular pad along W of a channels-last tensor (latent boundary of the VAE decode,
 //      pipeline_animation_inference_dual.py:349-357, 813-815) ----------------------------------------
 template <typename T>
@@ -357,6 +535,44 @@ extern "C" int im360_groupnorm_apply_cat(const void* xa, const void* xb, const v
     ProfScope prof(PROF_GN_APPLY, stream);
     if (dtype == 0) launch_gn_apply<__bf16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
     else launch_gn_apply<_Float16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// GroupNorm (+ SiLU, + circular W pad, on x or on the never-materialised concatenation [xa | xb]) in ONE launch: statistics,
+// their reduction and the normalisation pass of gn_fused_kernel.  partial: fp32 workspace of N * S * 2 * (C1 + C2) floats,
+// S = im360_gn_num_slabs(N, H, W); counter: N int32 (zeroed here, on the stream).  xb may be null (C2 = 0).  Same bits as
+// im360_groupnorm_stats + im360_groupnorm_apply.
+// Replaces: InflatedGroupNorm / nn.GroupNorm (+ F.silu, + pad_pano) as the two functions above; one pass over HBM less.
+extern "C" int im360_groupnorm_fused(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
+                                     void* counter, void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2,
+                                     int64_t G, int64_t pad, float eps, int act, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(xa && gamma && beta && partial && counter && y, "groupnorm_fused: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && G > 0 && (xb != nullptr) == (C2 > 0), "groupnorm_fused: bad problem");
+    IM360_CHECK_ARG((C1 % 8) == 0 && (C2 % 8) == 0 && ((C1 + C2) % G) == 0, "groupnorm_fused: C1=%ld, C2=%ld must be multiples of 8 and C1 + C2 of G=%ld", (long)C1, (long)C2, (long)G);
+    IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_fused: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)y % 16) == 0, "groupnorm_fused: misaligned pointer");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_fused: dtype %d unsupported", dtype);
+    const int S = pick_slabs(N, H * W);
+    IM360_CHECK_ARG(N * S <= 0x7fffffffL, "groupnorm_fused: grid too large");
+    const int C = (int)(C1 + C2);
+    const size_t dyn = (size_t)2 * C * sizeof(float);
+    IM360_CHECK_ARG(dyn <= 48 * 1024, "groupnorm_fused: C=%d too wide for the LDS scale / shift table", C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PROF_GN_APPLY, stream);
+    if (hipMemsetAsync(counter, 0, (size_t)N * sizeof(int), s) != hipSuccess) {
+        im360_set_error("groupnorm_fused: hipMemsetAsync failed");
+        return IM360_ERR_LAUNCH;
+    }
+    if (dtype == 0)
+        hipLaunchKernelGGL((gn_fused_kernel<__bf16>), dim3((unsigned)(N * S)), dim3(256), dyn, s, (const __bf16*)xa, (const __bf16*)xb, (int)C1, (int)C2,
+                           (float*)partial, (int*)counter, (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)y, (int)H, (int)W, (int)G,
+                           (int)pad, act, S, eps, C);
+    else
+        hipLaunchKernelGGL((gn_fused_kernel<_Float16>), dim3((unsigned)(N * S)), dim3(256), dyn, s, (const _Float16*)xa, (const _Float16*)xb, (int)C1, (int)C2,
+                           (float*)partial, (int*)counter, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)y, (int)H, (int)W, (int)G,
+                           (int)pad, act, S, eps, C);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

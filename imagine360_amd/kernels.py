@@ -25,6 +25,7 @@ _SIGNATURES = {
     "im360_groupnorm_stats": (_INT, [_PTR] * 6 + [_I64] * 6 + [_F32, _INT, _PTR]),
     "im360_groupnorm_apply": (_INT, [_PTR] * 4 + [_I64] * 5 + [_INT, _INT, _PTR]),
     "im360_groupnorm_stats_cat": (_INT, [_PTR] * 7 + [_I64] * 7 + [_F32, _INT, _PTR]),
+    "im360_groupnorm_fused": (_INT, [_PTR] * 7 + [_I64] * 7 + [_F32, _INT, _INT, _PTR]),
     "im360_groupnorm_apply_cat": (_INT, [_PTR] * 5 + [_I64] * 6 + [_INT, _INT, _PTR]),
     "im360_conv1x1_cat_fwd": (_INT, [_PTR] * 6 + [_I64] * 6 + [_INT, _PTR]),
     "im360_linear_fwd": (_INT, [_PTR] * 6 + [_I64] * 3 + [_INT, _PTR]),
@@ -279,9 +280,31 @@ def group_norm_apply(x, scale, shift, silu, pad=0):
     return y
 
 
+GN_FUSED = True          # group_norm(): one launch (statistics + reduction + normalisation); False: the three-kernel path (A/B, same bits)
+
+
 def group_norm(x, gamma, beta, groups, eps, silu=False, pad=0):
-    scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
-    return group_norm_apply(x, scale, shift, silu, pad)
+    """act(GroupNorm(x)) [N, H, W + 2 pad, C]; x [N, H, W, C] or a pair standing for a channel concatenation.  One launch
+    (``im360_groupnorm_fused``: the second read of every slab comes from the caches, 2 HBM passes instead of 3)."""
+    if not GN_FUSED:
+        scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
+        return group_norm_apply(x, scale, shift, silu, pad)
+    xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+    _dev(xa, xb, gamma, beta)
+    N, H, W, C1 = xa.shape
+    C2 = xb.shape[-1] if xb is not None else 0
+    C = C1 + C2
+    assert xa.is_contiguous() and gamma.dtype == xa.dtype and beta.dtype == xa.dtype and gamma.numel() == C
+    assert xb is None or (xb.is_contiguous() and xb.shape[:3] == xa.shape[:3] and xb.dtype == xa.dtype)
+    S = lib().im360_gn_num_slabs(N, H, W)
+    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=xa.device)
+    counter = torch.empty((N,), dtype=torch.int32, device=xa.device)
+    y = torch.empty((N, H, W + 2 * pad, C), dtype=xa.dtype, device=xa.device)
+    rc = lib().im360_groupnorm_fused(_p(xa), _p(xb), _p(gamma), _p(beta), _p(partial), _p(counter), _p(y), N, H, W, C1, C2,
+                                     groups, pad, float(eps), int(bool(silu)), _dt(xa), _stream())
+    _check(rc, "im360_groupnorm_fused")
+    _count("gn_apply", 0.0, xa.element_size() * (N * H * W * C + y.numel()))          # algorithmic: x read once, y written once
+    return y
 
 
 # ------------------------------------------------------------------------------------------ convolution

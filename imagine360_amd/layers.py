@@ -95,8 +95,7 @@ class InflatedGroupNorm(nn.GroupNorm):
         return kernels.group_norm_stats(x, self.weight, self.bias, self.num_groups, self.eps, pad)
 
     def forward_cl(self, x, silu=False, pad=0):
-        scale, shift = self.stats_cl(x, pad)
-        return kernels.group_norm_apply(x, scale, shift, silu, pad)
+        return kernels.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu=silu, pad=pad)
 
     def forward(self, x):
         if x.dim() == 5:

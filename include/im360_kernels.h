@@ -104,6 +104,17 @@ int im360_groupnorm_apply_cat(const void* xa, const void* xb, const void* scale,
                               int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t pad, int act,
                               int dtype, void* stream);
 
+/* The whole GroupNorm (+ SiLU, + circular W pad; on x or on the never-materialised concatenation [xa | xb], xb may be null
+ * with C2 = 0) in ONE launch: per-slab partial sums, a per-image arrival counter, every workgroup reduces its image's
+ * partials in the fixed order of the two-kernel path (same bits) and normalises its slab -- whose second read comes out of
+ * the L2 / Infinity Cache microseconds after the first: 2 HBM passes instead of 3.  partial: N * S * 2 * (C1 + C2) floats
+ * with S = im360_gn_num_slabs(N, H, W); counter: N int32 (zeroed by the call, on the stream).
+ * Replaces: InflatedGroupNorm / nn.GroupNorm + F.silu + pad_pano, animatediff/models/resnet.py:9-17, 221-243;
+ *   attention.py:262; motion_module.py:169; unet.py conv_norm_out; src/utils/pano.py:75-95. */
+int im360_groupnorm_fused(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial, void* counter,
+                          void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t G, int64_t pad,
+                          float eps, int act, int dtype, void* stream);
+
 /* 3x3 (ntaps = 9) or 1x1 (ntaps = 1) convolution, implicit GEMM on MFMA.  x [N, Hin, Win, Cin],
  * y [N, Hout, Wout, Cout], w_packed from im360_pack_conv_weight.  stride 1|2; up: input is
  * nearest-upsampled x2 on the fly; wrap: circular W addressing; x_off / y_off: column / row offset of the

@@ -219,6 +219,63 @@ def gen_mvxf():
     save("mv_forward_w5_xf.npz", pano=o["pano"], pers_views=o["pers_views"])
 
 
+def gen_mvfull():
+    """FULL-WIDTH dual-branch forward (320 / 640 / 1280 / 1280 channels, xformers semantics) of the REAL reference at the
+    shapes of BASELINE cfg1 (8 frames, 256x512 equirect, 20 views, CFG batch 2) on the filler weights ROUNDED TO bf16 and
+    bf16-rounded activations inputs (what a bf16 product run sees), fp32 arithmetic.  Written as fp16 (2^-11 relative, far
+    below the 1e-2 it is compared at).  Also checks the oracle against the reference at full width, and stores what 16-bit
+    storage ALONE costs on this network (the oracle with every primitive's output rounded, im360_oracle.unet.storage): the
+    calibration of the GPU test's bound, computed here so that the GPU box does not spend minutes of host time on it.
+    Plus one full-width VAE decode of a 32x64 latent through the real AutoencoderKL."""
+    print("[mvfull] full-width reference forward at cfg1 shapes (a few minutes)")
+    bf = torch.bfloat16
+    cfg = sd21_unet_cfg(1)
+    cfg.xformers = True
+    mv = RB.ref_mv(cfg)
+    for prm in mv.parameters():
+        prm.data = prm.data.to(bf).float()
+    for mod in mv.modules():
+        if mod.__class__.__name__ == "IPCrossAttention":
+            mod._use_memory_efficient_attention_xformers = True
+    inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=1, sam_frames=16)
+    inp = {k: (v.to(bf).float() if torch.is_floating_point(v) and k not in S.FP32_INPUTS else v) for k, v in inp.items()}
+    cams = S.icosahedron_cameras(90, 128)
+    torch.manual_seed(7)
+    random.seed(7)
+    t0 = time.time()
+    rp, rn = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **inp)
+    print(f"  reference forward {time.time() - t0:.1f}s")
+    sd = dict(mv.state_dict())
+    del mv
+    args = (sd, cfg, inp["latents"], inp["pano_latent"], inp["timestep"], inp["prompt_embd"], inp["pano_prompt_embd"], cams,
+            inp["fps_tensor_pano"], inp["fps_tensor_pers"], inp["reference_images_clip_feat_pano"],
+            inp["reference_images_clip_feat_pers"], inp["relative_position_tensor"], inp["pitchs_tensor"])
+    masks = {}
+    torch.manual_seed(7)
+    random.seed(7)
+    op_, on = OMV.mv_forward(*args, mask_cache=masks)
+    check("mvfull pers", op_, rp)
+    check("mvfull pano", on, rn)
+    cal = {}
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(7)
+        random.seed(7)
+        with OU.storage(dt):
+            cp, cn = OMV.mv_forward(*args, mask_cache=masks)
+        cal[dt] = (rel(cn, rn), rel(cp, rp))
+        print(f"  storage-only {dt}: pano {cal[dt][0]:.3e} pers {cal[dt][1]:.3e}")
+    del sd
+    vcfg = sd21_vae_cfg(1)
+    vae = RB.ref_vae(vcfg)
+    for prm in vae.parameters():
+        prm.data = prm.data.to(bf).float()
+    z = torch.randn(1, 4, 32, 64, generator=torch.Generator().manual_seed(9)).to(bf).float()
+    dec = vae.decode(z).sample
+    check("vaefull decode", OV.decode(dict(vae.state_dict()), vcfg, z), dec)
+    save("mv_forward_full_cfg1.npz", pano=rn.half(), pers=rp.half(), vae_decode=dec.half(),
+         storage_only_bf16=torch.tensor(cal[torch.bfloat16]), storage_only_fp16=torch.tensor(cal[torch.float16]))
+
+
 def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=None, motion_heads=8):
     print("[pipeline]", name)
     R = ref_shims.ref_modules()
@@ -410,7 +467,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad", "preproc"]      # "pipeline25": ~25 min, on request
+    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad", "preproc"]      # "pipeline25": ~25 min, "mvfull": ~10 min, on request
     os.makedirs(GOLD, exist_ok=True)
     for w in which:
         globals()["gen_" + w]()

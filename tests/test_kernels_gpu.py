@@ -720,3 +720,27 @@ def test_ring_kernel_cout_groups_are_bit_identical():
             assert torch.equal(K.linear(x, lw, 1280), lref), ng
     finally:
         K.tuning_set("ring_groups", 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C1,C2,pad,silu", [(640, 32, 32, 320, 0, 0, True), (32, 64, 128, 320, 0, 2, True), (640, 16, 16, 1280, 640, 0, True),
+                                                   (3, 8, 16, 64, 64, 0, False), (5, 4, 4, 1280, 0, 0, False), (2, 6, 10, 320, 320, 2, True)])
+def test_group_norm_single_launch_equals_the_three_kernel_path(dt, N, H, W, C1, C2, pad, silu):
+    """im360_groupnorm_fused (statistics, per-image arrival counter, in-kernel reduction, normalisation: one launch, the
+    slab's second read from the caches) produces the SAME BITS as statistics kernel + finalize + apply, at grid sizes far
+    above what is resident at once (2560 workgroups: the waiting scheme's liveness), on skip pairs and with the pad-aware
+    statistics; run twice (the counter is re-zeroed by every call)."""
+    xa = (rnd(N, H, W, C1, seed=95) * 1.3 + 0.4).to(dt).cuda()
+    xb = (rnd(N, H, W, C2, seed=96) * 0.7).to(dt).cuda() if C2 else None
+    C = C1 + C2
+    gamma, beta = (1 + 0.1 * rnd(C, seed=97)).to(dt).cuda(), (0.1 * rnd(C, seed=98)).to(dt).cuda()
+    x = (xa, xb) if C2 else xa
+    try:
+        K.GN_FUSED = False
+        want = K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad)
+        K.GN_FUSED = True
+        for _ in range(2):
+            got = K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad)
+            assert got.shape == (N, H, W + 2 * pad, C) and torch.equal(got, want)
+    finally:
+        K.GN_FUSED = True

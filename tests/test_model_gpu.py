@@ -30,7 +30,8 @@ def test_mv_forward_vs_oracle(dt, tol):
     """One dual-branch forward (~60 layers, 7 WarpAttn) at channels / 5 against the fp32 oracle, the real reference's
     fixture and the taps after every WarpAttn.  The bound is CALIBRATED: the oracle with every primitive's output and the
     residual stream rounded to the 16-bit dtype (im360_oracle.unet.storage: fp32 arithmetic, no kernel involved) measures
-    what storage alone costs on this network (1.7e-2 in bf16, 2.1e-3 in fp16); the product must stay within 1.5x of it."""
+    what storage alone costs on this network (1.7e-2 in bf16, 2.1e-3 in fp16); the product must stay within 1.25x of it
+    (measured: 1.01 - 1.02x -- the kernels add a few per cent to the rounding of the stored tensors)."""
     from im360_oracle import unet as OU
     dev = torch.device("cuda", 0)
     mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True)
@@ -65,7 +66,7 @@ def test_mv_forward_vs_oracle(dt, tol):
     cal = dict(storage_only_pano=rel(c_pano, o_pano), storage_only_pers=rel(c_pers, o_pers))
     _record(f"mv_forward_w5_{str(dt).split('.')[-1]}", **errs, **cal)
     assert max(errs.values()) < tol, errs
-    assert errs["pano"] <= 1.5 * cal["storage_only_pano"] and errs["pers"] <= 1.5 * cal["storage_only_pers"], (errs, cal)
+    assert errs["pano"] <= 1.25 * cal["storage_only_pano"] and errs["pers"] <= 1.25 * cal["storage_only_pers"], (errs, cal)   # measured 1.01 - 1.02x
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-2), (torch.float16, 5e-3)])
@@ -285,23 +286,30 @@ def test_full_width_block_vs_oracle(dt, tol, level, c, heads, hw, routed):
         assert errs[k] <= 1.25 * v + 1e-4, (k, errs, cal)       # (round 2 measured 1.03 - 1.04x on every block)
 
 
-def test_full_width_cfg1_step_and_vae_frame_vs_oracle():
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_full_width_cfg1_step_and_vae_frame_vs_reference_fixture(dt):
     """ONE FULL-WIDTH dual-branch forward (both UNets at 320 / 640 / 1280 / 1280 channels, 7 WarpAttn, CFG batch 2) at the
-    shapes of BASELINE cfg1 (8 frames, 256x512 equirect, 20 views) on the GPU against the fp32 oracle on the same weights
-    and seeds (~1 min of host time) -- the whole-step comparison the reduced-width model tests cannot give -- in two
-    routings: the production rule, and with the token-major GEMMs forced onto the MFMA kernel from 16 384 tokens so that
-    the statistics-writing / LayerNorm-folded / skip-pair kernels run inside the full model at level 0 and 1 of both
-    branches.  The bound is calibrated: the oracle with every primitive's output rounded to bf16 (no kernel involved)
-    measures what storage alone costs on this network; the product must stay within 1.5x of it.
-    Plus one full-width VAE decode of a 32x64 latent (a 256x512 frame) against the oracle."""
+    shapes of BASELINE cfg1 (8 frames, 256x512 equirect, 20 views) on the GPU against what the REAL reference computed in
+    fp32 for the same bf16-rounded weights, inputs and seeds (tests/golden/mv_forward_full_cfg1.npz, written by
+    oracle/tools/gen_golden.py mvfull, which also checks the oracle against the reference at full width: 2e-6) -- the
+    whole-step comparison the reduced-width model tests cannot give -- in two routings: the production rule, and with the
+    token-major GEMMs forced onto the MFMA kernel from 16 384 tokens so that the statistics-writing / LayerNorm-folded /
+    skip-pair kernels run inside the full model at level 0 and 1 of both branches.
+    The bound is calibrated: the fixture carries what 16-bit storage ALONE costs on this network (the oracle with every
+    primitive's output rounded, no kernel involved: 8.9e-3 / 9.9e-3 in bf16); the product must stay within 1.25x of it
+    (measured 1.02x).  Plus one full-width VAE decode of a 32x64 latent (a 256x512 frame) against the real AutoencoderKL."""
     from imagine360_amd import layers
-    from im360_oracle import unet as OU
-    dt, dev = torch.bfloat16, torch.device("cuda", 0)
-    mv = configs.build_mv_model(1, device=dev, dtype=dt, xformers=True)
+    g = gold("mv_forward_full_cfg1.npz")
+    dev = torch.device("cuda", 0)
+    mv = configs.build_mv_model(1, device=dev, dtype=torch.bfloat16, xformers=True).to(dt)      # the fixture's weights: filler rounded to bf16
     mv.noise_on_host = True
     inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=1, sam_frames=16)
+    inp = {k: (v.to(torch.bfloat16) if torch.is_floating_point(v) and k not in S.FP32_INPUTS else v) for k, v in inp.items()}
     cams = S.icosahedron_cameras(90, 128)
-    dinp = S.cast_mv_inputs(inp, dev, dt)          # (pitch / fps / crop rectangle stay float32, as in the pipeline)
+    dinp = S.cast_mv_inputs(inp, dev, dt)
+    o_pers, o_pano = g["pers"].float(), g["pano"].float()
+    cal_pano, cal_pers = (float(v) for v in g["storage_only_bf16" if dt == torch.bfloat16 else "storage_only_fp16"])
+    errs = {"storage_only_pano": cal_pano, "storage_only_pers": cal_pers}
     outs = {}
     for name, min_tokens in (("production_routing", layers.ROUTE_MIN_TOKENS), ("mfma_routing_from_16k_tokens", 16384)):
         saved = layers.ROUTE_MIN_TOKENS
@@ -313,42 +321,23 @@ def test_full_width_cfg1_step_and_vae_frame_vs_oracle():
             outs[name] = (pers.float().cpu(), pano.float().cpu())
         finally:
             layers.ROUTE_MIN_TOKENS = saved
-    cfg = sd21_unet_cfg(1)
-    cfg.xformers = True
-    sd = {k: v.float().cpu() for k, v in mv.state_dict().items()}
-    del mv
-    torch.cuda.empty_cache()
-    args = lambda: (sd, cfg, _q(inp["latents"], dt), _q(inp["pano_latent"], dt), inp["timestep"], _q(inp["prompt_embd"], dt),
-                    _q(inp["pano_prompt_embd"], dt), cams, inp["fps_tensor_pano"], inp["fps_tensor_pers"],
-                    _q(inp["reference_images_clip_feat_pano"], dt), _q(inp["reference_images_clip_feat_pers"], dt),
-                    inp["relative_position_tensor"], inp["pitchs_tensor"])
-    masks = {}
-    torch.manual_seed(7)
-    random.seed(7)
-    o_pers, o_pano = OMV.mv_forward(*args(), mask_cache=masks)
-    torch.manual_seed(7)
-    random.seed(7)
-    with OU.storage(dt):
-        c_pers, c_pano = OMV.mv_forward(*args(), mask_cache=masks)
-    errs = {"storage_only_pano": rel(c_pano, o_pano), "storage_only_pers": rel(c_pers, o_pers)}
     for name, (pers, pano) in outs.items():
         errs[name + "_pano"], errs[name + "_pers"] = rel(pano, o_pano), rel(pers, o_pers)
         # no single view / frame may be off: the worst (view, frame) slice of the perspective prediction
         d = (pers - o_pers).flatten(3).norm(dim=(2, 3)) / o_pers.flatten(3).norm(dim=(2, 3))
         errs[name + "_worst_view"] = float(d.max())
     errs["routings_agree"] = rel(outs["mfma_routing_from_16k_tokens"][1], outs["production_routing"][1])
-    del sd
-    vae = configs.build_vae(1, device=dev, dtype=dt)
-    vsd = {k: v.float().cpu() for k, v in vae.state_dict().items()}
-    z = torch.randn(1, 4, 32, 64, generator=torch.Generator().manual_seed(9))
-    errs["vae_decode_full_width"] = rel(vae.decode(z.to(dev, dt)).sample, OV.decode(vsd, sd21_vae_cfg(1), _q(z, dt)))
-    _record("full_width_cfg1_step_bf16", **errs)
+    del mv
+    torch.cuda.empty_cache()
+    vae = configs.build_vae(1, device=dev, dtype=torch.bfloat16).to(dt)
+    z = torch.randn(1, 4, 32, 64, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    errs["vae_decode_full_width"] = rel(vae.decode(z.to(dev, dt)).sample, g["vae_decode"].float())
+    _record(f"full_width_cfg1_step_{str(dt).split('.')[-1]}", **errs)
     for name in outs:
-        assert errs[name + "_pano"] <= 1.5 * errs["storage_only_pano"] + 1e-3, errs
-        assert errs[name + "_pers"] <= 1.5 * errs["storage_only_pers"] + 1e-3, errs
-        assert errs[name + "_worst_view"] <= 3 * errs["storage_only_pers"] + 1e-3, errs
-    assert max(v for k, v in errs.items() if k.endswith(("_pano", "_pers"))) < 6e-2, errs
-    assert errs["vae_decode_full_width"] < 3e-2, errs
+        assert errs[name + "_pano"] <= 1.25 * cal_pano + 2e-4, errs
+        assert errs[name + "_pers"] <= 1.25 * cal_pers + 2e-4, errs
+        assert errs[name + "_worst_view"] <= 2 * cal_pers + 2e-4, errs
+    assert errs["vae_decode_full_width"] < (2e-2 if dt == torch.bfloat16 else 3e-3), errs
 
 
 def test_cfg5_sized_kernels_fp16():
@@ -509,6 +498,59 @@ def test_ops_vs_reference_fixture(dt, tol):
     errs["conv_in_pano"] = rel(from_cl(un.conv_in_cl(l9, pano=True), f), g["conv_in_pano"])
     _record(f"ops_w5_{str(dt).split('.')[-1]}", **errs)
     assert max(errs.values()) < tol, errs
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2.5e-2), (torch.float16, 3.5e-3)])
+def test_single_branch_unet_forward_on_the_kernels(dt, tol):
+    """SURVEY row a21 on the GPU: ``UNet3DConditionModel.forward`` (the kept single-branch API: reference layout in / out,
+    IP-adapter conditioning and fps embedding inside) through the HIP kernels against the SAME host code on exact fp32
+    stand-in kernels (tests/_emu_kernels.py; that pairing is pinned on the real reference's forward to 2e-6 by the CPU
+    tier).  The bound is the 16-bit storage error of a ~60-layer forward."""
+    import _emu_kernels as E
+    dev = torch.device("cuda", 0)
+    un = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True).pano_unet
+    ref = configs.build_mv_model(5, device="cpu", dtype=dt, xformers=True).pano_unet.float()       # same 16-bit weights, fp32 math
+    g = torch.Generator().manual_seed(17)
+    x = _q(torch.randn(2, 9, 8, 16, 32, generator=g), dt)
+    ctx = _q(torch.randn(2, 77, 1024, generator=g), dt)
+    feat = _q(torch.randn(2, 16, 4096, 256, generator=g), dt)
+    kw = dict(use_ip_plus_cross_attention=True, use_fps_condition=True, fps_tensor=torch.tensor([8.0]))
+    out = un(x.to(dev, dt), 981, ctx.to(dev, dt), reference_images_clip_feat=feat.to(dev, dt), **kw).sample
+    with E.patched_kernels():
+        want = ref(x, 981, ctx, reference_images_clip_feat=feat, **kw).sample
+    err = rel(out, want)
+    _record(f"unet_forward_w5_{str(dt).split('.')[-1]}", rel=err)
+    assert out.shape == (2, 4, 8, 16, 32) and torch.isfinite(out.float()).all() and err < tol, err
+
+
+def test_cross_view_masks_and_tables_on_the_device_match_the_reference_fixture():
+    """SURVEY row a12 on the GPU: the cached per-resolution geometry WarpAttn uploads once -- both additive mask matrices
+    (normal and antipodal), as handed to the attention kernel (16-bit, and the packed fp16 * log2(e) form), and the
+    spherical positional tables -- against the REAL reference's masks (tests/golden/masks.npz) and the host-built tables."""
+    from imagine360_amd import pano_geometry as G
+    from imagine360_amd.mv_model import WarpAttn
+    g = gold("masks.npz")
+    dev = torch.device("cuda", 0)
+    ph, eh, m = 8, 16, 20
+    cams = {k: v[0] for k, v in S.icosahedron_cameras(90, ph * 8).items()}
+    blk = WarpAttn(64).to(dev)
+    ne, npx = eh * 2 * eh, ph * ph
+    for tag in ("normal", "oppo"):
+        b_e2p, b_p2e, pers_pe, equi_pe, packed = blk.geometry(ph, ph, eh, 2 * eh, cams, tag == "oppo", dev, torch.bfloat16)
+        ref_e2p = g[f"pers_{tag}_{ph}"].reshape(m, ne, npx).permute(1, 0, 2).reshape(ne, m * npx)
+        ref_p2e = g[f"equi_{tag}_{ph}"].reshape(m * npx, ne)
+        assert packed and b_e2p.dtype == torch.float16 and b_e2p.is_cuda and b_e2p.shape == (ne, m * npx)
+        # packed form = fp16(bf16(mask) * log2 e): undo the scale, allow the two roundings
+        assert (b_e2p.float().cpu() / 1.4426950408889634 - ref_e2p).abs().max() < 6e-3
+        assert (b_p2e.float().cpu() / 1.4426950408889634 - ref_p2e).abs().max() < 6e-3
+        pc, ec = G.spherical_coords(ph, ph, eh, 2 * eh, cams)
+        assert torch.equal(pc, g[f"pers_coords_{ph}"]) and torch.equal(ec, g[f"equi_coords_{ph}"])
+        from im360_oracle import geometry as OG
+        assert (pers_pe.float().cpu() - OG.spherical_pe(pc, 16).reshape(-1, 64)).abs().max() < 5e-3     # bf16 table of values in [-1, 1]
+        assert (equi_pe.float().cpu() - OG.spherical_pe(ec, 16).reshape(-1, 64)).abs().max() < 5e-3
+    # the cache returns the resident tensors (no rebuild, no upload) on the second call
+    again = blk.geometry(ph, ph, eh, 2 * eh, cams, False, dev, torch.bfloat16)
+    assert again[0].data_ptr() == blk.geometry(ph, ph, eh, 2 * eh, cams, False, dev, torch.bfloat16)[0].data_ptr()
 
 
 def test_preprocessing_warps_vs_oracle():
