@@ -252,25 +252,28 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ xa,
                     for (int l = 1; l < lanes; ++l)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) acc[e] += red[(l * ncp + cc) * 16 + e];
+                    // published WRITE-THROUGH (relaxed agent-scope stores = `sc1`): the consumers are other workgroups, possibly
+                    // on another XCD (private L2); a release fence instead would write back the whole L2 -- full of other
+                    // workgroups' freshly normalised output -- once per workgroup (measured: 0.91 ms against 0.26 ms)
                     float* dst = partial + ((long)(n * S + s) * 2) * C + coff + (c0 + cc) * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        dst[e] = acc[e];
-                        dst[C + e] = acc[8 + e];
+                        __hip_atomic_store(dst + e, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + C + e, acc[8 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
         }
     }
-    // ---- arrive, wait for the image's other slabs
-    __threadfence();
+    // ---- arrive (every write-through store of this workgroup has been acknowledged: vmcnt(0) in each thread, then the
+    //      barrier), wait for the image's other slabs.  No fences: the partials are read back with `sc1` loads below.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_fetch_add(counter + n, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter + n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(4);
+        __hip_atomic_fetch_add(counter + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // ---- (2) scale / shift of every channel of image n: one wave per group at a time, gn_finalize_kernel's order
     {
         const int lane = tid & 63, wave = tid >> 6;
@@ -282,8 +285,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ xa,
             for (int i = lane; i < S * cpg; i += 64) {
                 const int sl = i / cpg, j = i % cpg;
                 const float* src = base + (long)sl * 2 * C + j;
-                sum += (double)__builtin_nontemporal_load(src);
-                sq += (double)__builtin_nontemporal_load(src + C);
+                sum += (double)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sq += (double)__hip_atomic_load(src + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {

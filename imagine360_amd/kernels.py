@@ -280,12 +280,17 @@ def group_norm_apply(x, scale, shift, silu, pad=0):
     return y
 
 
-GN_FUSED = True          # group_norm(): one launch (statistics + reduction + normalisation); False: the three-kernel path (A/B, same bits)
+# group_norm(): True = ONE launch (im360_groupnorm_fused: statistics, per-image arrival counter, in-kernel reduction,
+# normalisation; same bits).  Measured SLOWER than the three-kernel path -- 0.299 vs 0.264 ms on 640 x 32x32x320, 0.315 vs
+# 0.101 ms on 32 x 64x128x320 (64 slabs per image wait for each other) -- the arrival waits and the write-through publish
+# of the partials cost more than the HBM pass the cache-resident second read saves; and it must not be captured in a
+# hipGraph together with kernels it could wait behind.  Kept as an A/B variant, off.
+GN_FUSED = False
 
 
 def group_norm(x, gamma, beta, groups, eps, silu=False, pad=0):
-    """act(GroupNorm(x)) [N, H, W + 2 pad, C]; x [N, H, W, C] or a pair standing for a channel concatenation.  One launch
-    (``im360_groupnorm_fused``: the second read of every slab comes from the caches, 2 HBM passes instead of 3)."""
+    """act(GroupNorm(x)) [N, H, W + 2 pad, C]; x [N, H, W, C] or a pair standing for a channel concatenation: statistics
+    kernel + finalize + apply (or, with ``GN_FUSED``, the single-launch variant -- see the note at the flag)."""
     if not GN_FUSED:
         scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
         return group_norm_apply(x, scale, shift, silu, pad)

@@ -743,4 +743,4 @@ def test_group_norm_single_launch_equals_the_three_kernel_path(dt, N, H, W, C1, 
             got = K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad)
             assert got.shape == (N, H, W + 2 * pad, C) and torch.equal(got, want)
     finally:
-        K.GN_FUSED = True
+        K.GN_FUSED = False

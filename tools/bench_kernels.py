@@ -170,6 +170,7 @@ def bench_gn(iters):
         by = N * H * W * C * 2.0
         K.GN_FUSED = True
         t3 = timeit(lambda: K.group_norm(x, g, b, 32, 1e-5, silu=True, pad=pad), iters)
+        K.GN_FUSED = False
         print(f"gn    {name:14s} N={N:3d} {H}x{W} C={C:4d}: stats {t1 * 1e3:7.3f} ms {by / t1 / 1e9:6.0f} GB/s | apply {t2 * 1e3:7.3f} ms "
               f"{2 * by / t2 / 1e9:6.0f} GB/s | one launch {t3 * 1e3:7.3f} ms (stats + apply {1e3 * (t1 + t2):7.3f}), {2 * by / t3 / 1e9:6.0f} GB/s algorithmic")
 
