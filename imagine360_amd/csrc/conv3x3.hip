@@ -301,7 +301,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 for (int g = 0; g < 4; ++g) {
                     const int co = nw0 + a * 32 + 8 * g + 4 * hi;
                     const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
-                    wb[g] = *(const uint2*)(bsrc + cc * bmul);
+                    if constexpr (EPI == 2 || EPI == 5) {
+                        // (the persistent kernel staged the tile's bias slice in LDS; other callers pass no cvec)
+                        wb[g] = cvec ? *(const uint2*)((const char*)cvec + (co - n0) * 2) : *(const uint2*)(bsrc + cc * bmul);
+                    } else {
+                        wb[g] = *(const uint2*)(bsrc + cc * bmul);
+                    }
                     if constexpr (EPI == 0) wt[g] = *(const uint2*)(tsrc + (toff + cc) * tmul);      // (token-major linears have no temb)
                 }
 #pragma unroll
@@ -722,7 +727,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
     constexpr int RING_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
     constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
-    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : 0);
+    constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (T-typed, BN entries)
+    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0));
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     float* cvec = (float*)(lds + RING_BYTES);
@@ -888,6 +894,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 f32x4 val = *(const f32x4*)((v ? p.ln_c2 : p.ln_c1) + n0 + idx);
                 if (v && p.ln_tab) val += *(const f32x4*)(p.ln_tab + ((m0 / p.tab_div) % p.tab_mod) * (long)p.Cout + n0 + idx);
                 *(f32x4*)(cvec + v * BN + idx) = val;
+            }
+        }
+        if constexpr (BIAS_LDS) {
+            // the tile's bias slice -> LDS: the epilogue's five rounds per 32-row block each started with a dependent global
+            // load (an L2 round trip the ten-phase K loop of these GEMMs cannot hide)
+            if (tid < BN / 8) {
+                const uint4 v = p.bias ? *(const uint4*)((const T*)p.bias + n0 + tid * 8) : uint4{0u, 0u, 0u, 0u};
+                *(uint4*)((char*)cvec + tid * 16) = v;
             }
         }
         if (nph > 2) issue(2);
