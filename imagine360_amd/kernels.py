@@ -382,7 +382,7 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
                               N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
                               imgs_per_temb, _dt(x), _stream())
     _check(rc, "im360_conv_fwd")
-    if STATS is not None:
+    if STATS is not None or SHAPES is not None:
         es = x.element_size()
         linear = taps == 1 and Hin == 1 and Win == 1
         _count("gemm" if linear else "conv", 2.0 * N * hout * wout * Cin * cout * taps,
