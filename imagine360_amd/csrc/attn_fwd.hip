@@ -44,6 +44,9 @@ struct AttnParams {
     int Nk2;
     long k2_bs, k2_rs, v2_bs, v2_rs;
     float out_scale2;
+    // resident-K/V cross attention (xattn_resident_kernel): query blocks (32 rows) per image, per (K/V batch, head) pair, in total
+    int x_nqb, x_bpp;
+    long x_total;
 };
 
 constexpr int KVB = 64;            // keys per LDS tile
@@ -60,7 +63,10 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // instruction), parks them in its own 4 KiB of LDS (XOR-swizzled, conflict-free both ways) and reads the per-lane fragments
 // from there.  Measured on WarpAttn level 1: 1.016 vs 0.958 ms -- the divergent loads are NOT what limits the kernel (the
 // hypothesis was one cache-line lookup per cycle on the vector memory path); kept as an A/B variant, identical bits.
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false>
+// DS ("dot sums", knob attn_ds): the row sums are taken over the ROUNDED weights -- the packed P words the PV product uses -- with
+// eight v_dot2c against (1, 1) per 16 scores instead of sixteen v_add, and the two half-waves exchange their maxima through
+// v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip whose lgkmcnt wait also drains the prefetched fragments).
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
@@ -334,7 +340,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int kb = K0; kb < K1; ++kb)
 #pragma unroll
                 for (int r = (kb == K0 ? 1 : 0); r < 16; ++r) mloc = fmaxf(mloc, s[qb][kb][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            if constexpr (DS) {
+                // own and partner value in either order (max is symmetric)
+                const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, mloc), __builtin_bit_cast(uint32_t, mloc), false, false);
+                mloc = fmaxf(__builtin_bit_cast(float, e.x), __builtin_bit_cast(float, e.y));
+            } else {
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            }
             // deferred rescale: the running max only moves when these keys exceed it by more than RESCALE_THR (log2
             // units; P stays <= 2^THR), so the O / l rescale and the refresh of the -max block are rare.  The very
             // first keys always set it.
@@ -364,10 +376,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
-                    lsum += pv[r];
+                    if constexpr (!DS) lsum += pv[r];
+                }
+                const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
+                if constexpr (DS) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        lsum = dot2_acc<T>(pf[c].x, Elem<T>::ones2, lsum);
+                        lsum = dot2_acc<T>(pf[c].y, Elem<T>::ones2, lsum);
+                        lsum = dot2_acc<T>(pf[c].z, Elem<T>::ones2, lsum);
+                        lsum = dot2_acc<T>(pf[c].w, Elem<T>::ones2, lsum);
+                    }
                 }
                 l_run[qb] += lsum;
-                const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
                 // O^T += V^T P^T: MFMA c covers the 16 keys 16c + {0..3, 8..11} + 4 hi (the C-fragment's own key
                 // order), gathered by two transposing reads; the two 32-channel accumulators alternate
 #pragma unroll
@@ -499,6 +520,228 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
+
+// ---- text + IP-adapter cross attention with BOTH key / value sets resident in LDS ---------------------------------------
+// Replaces the same call site as the DUAL kernel above (animatediff/models/attention.py:113-148: two independent softmaxes
+// of one query over the 77 text tokens and the 64 image tokens, summed with the adapter scale), for the shapes the model
+// runs: head dim 64, <= 96 + <= 64 keys, one context per video (kv_group = frames).  There the generic flash kernel is
+// launch / staging dominated (9 - 13 % of the MFMA peak): every 128-query workgroup stages the head's 36 KB of K / V for
+// 16 KB of Q, runs one or two ragged 64-key tiles with a barrier each and the online-softmax machinery those keys never need.
+// Here a workgroup stages the K / V of one (video, head) ONCE (K pre-multiplied by scale * log2(e), rows beyond the key
+// count zeroed) and its four waves then stream 32-query blocks of all that video's frames against it with no barrier and no
+// LDS write in the loop: per block 4 Q loads (the next block's are requested before this one's math), 20 QK^T + 18 PV MFMAs,
+// an exact two-pass softmax (the ragged text set is masked by an MFMA C operand of 0 / -inf, the row sums are dot2's of the
+// packed P), and the output stored as whole 16-byte pieces (the two half-waves trade half of their 8-byte fragments through
+// v_permlane32_swap).  Work is dealt as contiguous ranges of the (pair, frame, query block) sequence, so a workgroup
+// re-stages only when its range crosses into the next pair.  What is left is the HBM time of Q and O.
+template <typename T, int NB1, int NCH1, int NB2, bool RAG2, bool WIDE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 3, RAG2 ? 2 : 3))) void xattn_resident_kernel(AttnParams p) {
+    constexpr int D = 64, KP = D + 8, VP = 96, DC = D / 16, DV = D / 32;
+    constexpr int NKR = 32 * (NB1 + NB2);          // key rows held (set 2 starts at row 32 NB1)
+    __shared__ __attribute__((aligned(16))) T k_lds[NKR * KP];
+    __shared__ __attribute__((aligned(16))) T v_lds[NKR * VP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const long r0 = p.x_total * (long)blockIdx.x / (long)gridDim.x, r1 = p.x_total * ((long)blockIdx.x + 1) / (long)gridDim.x;
+
+    const int kfrag = col * KP + hi * 8;
+    const int l16 = lane & 15, half = (lane >> 4) & 1;
+    const int vfrag = (4 * hi + (l16 >> 2)) * VP + 16 * half + 4 * (l16 & 3);
+
+    // C operands that mask the keys past the end of a set: register r of lane (., hi) is key 32 (NB - 1) + row(r, hi)
+    f32x16 cmask1, cmask2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        cmask1[r] = 32 * (NB1 - 1) + mfma32_row(r, hi) >= p.Nk ? -INFINITY : 0.f;
+        cmask2[r] = RAG2 && 32 * (NB2 - 1) + mfma32_row(r, hi) >= p.Nk2 ? -INFINITY : 0.f;
+    }
+    static_assert(NCH1 > 2 * (NB1 - 1) && NCH1 <= 2 * NB1, "16-key chunks of the first set");
+
+    for (long j = r0; j < r1;) {
+        const long pair = j / p.x_bpp;
+        const long seg_end = r1 < (pair + 1) * p.x_bpp ? r1 : (pair + 1) * p.x_bpp;
+        const int bk = (int)(pair / p.H), h = (int)(pair % p.H);
+        // ---- stage this pair's K (scaled) and V, both sets; rows past a set's keys are zeros
+        __syncthreads();                     // every wave is done with the previous pair
+        for (int c = tid; c < NKR * (D / 8); c += 256) {
+            const int row = c / (D / 8), c8 = c % (D / 8);
+            const bool second = row >= 32 * NB1;
+            const int kr = second ? row - 32 * NB1 : row;
+            const bool real = kr < (second ? p.Nk2 : p.Nk);
+            const int krc = real ? kr : 0;
+            const T* ks = second ? (const T*)p.k2 + (long)bk * p.k2_bs + (long)krc * p.k2_rs : (const T*)p.k + (long)bk * p.k_bs + (long)krc * p.k_rs;
+            const T* vs = second ? (const T*)p.v2 + (long)bk * p.v2_bs + (long)krc * p.v2_rs : (const T*)p.v + (long)bk * p.v_bs + (long)krc * p.v_rs;
+            uint4 kk = *(const uint4*)(ks + h * D + c8 * 8), vv = *(const uint4*)(vs + h * D + c8 * 8);
+            float f[8];
+            unpack8<T>(kk, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2;
+            kk = pack8<T>(f);
+            if (!real) kk = vv = uint4{0u, 0u, 0u, 0u};
+            *(uint4*)(k_lds + row * KP + c8 * 8) = kk;
+            *(uint4*)(v_lds + row * VP + c8 * 8) = vv;
+        }
+        __syncthreads();
+
+        // ---- the wave's query blocks of this segment: jj, jj + 4, ... as (frame g, 32-row block qblk), advanced without divisions
+        const long base = pair * p.x_bpp;
+        const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+        auto q_src = [&](int g, int qblk, int& qrow_out, int& b_out) {
+            b_out = bk * p.kv_group + g;
+            const int row = qblk * 32 + col;
+            qrow_out = row;
+            return (const T*)p.q + (long)b_out * p.q_bs + (long)row * p.q_rs + h * D + hi * 8;      // (Nq % 32 == 0: no ragged block)
+        };
+        long jj = j + wid_s;
+        int g_cur = (int)((jj - base) / p.x_nqb), qblk_cur = (int)((jj - base) % p.x_nqb);
+        uint4 qf[DC], qn[DC];
+        int qrow = 0, qb_img = 0;
+        if (jj < seg_end) {
+            const T* qs = q_src(g_cur, qblk_cur, qrow, qb_img);
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) qf[dc] = *(const uint4*)(qs + dc * 16);
+        }
+        for (; jj < seg_end; jj += 4) {
+            // the next block's Q (the wave's last block re-requests itself: always-executed loads keep hipcc's waits counted)
+            int nrow, nimg;
+            if (jj + 4 < seg_end) {
+                qblk_cur += 4;
+                while (qblk_cur >= p.x_nqb) {
+                    qblk_cur -= p.x_nqb;
+                    ++g_cur;
+                }
+            }
+            const T* qs = q_src(g_cur, qblk_cur, nrow, nimg);
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) qn[dc] = *(const uint4*)(qs + dc * 16);
+            __builtin_amdgcn_sched_barrier(0);          // (hipcc sinks the requests to the middle of the block otherwise)
+
+            f32x16 osum[DV];
+            float inv2 = 0.f;
+            f32x16 o[DV];
+            // one key / value set: scores, exact softmax, O^T = V^T P^T; returns the row sum
+            auto run = [&](auto nbc, auto nchc, int kbase, const f32x16& cmask) {
+                constexpr int NB = decltype(nbc)::value, NCH = decltype(nchc)::value;      // NCH: 16-key chunks holding real keys
+                f32x16 s[NB];
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+                    for (int dc = 0; dc < DC; ++dc) {
+                        const uint4 a = *(const uint4*)(k_lds + kfrag + (kbase + kb * 32) * KP + dc * 16);
+                        if (dc == 0) {
+                            if (kb == NB - 1) s[kb] = Elem<T>::mfma32(a, qf[dc], cmask);
+                            else s[kb] = Elem<T>::mfma32(a, qf[dc], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+                        } else {
+                            s[kb] = Elem<T>::mfma32(a, qf[dc], s[kb]);
+                        }
+                    }
+                }
+                float m = s[0][0];
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                    for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) m = fmaxf(m, s[kb][r]);
+                {
+                    // both halves of the wave (keys 4 hi + ...): own and partner value in either order -- max is symmetric
+                    const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, m), __builtin_bit_cast(uint32_t, m), false, false);
+                    m = fmaxf(__builtin_bit_cast(float, e.x), __builtin_bit_cast(float, e.y));
+                }
+                float l = 0.f;
+#pragma unroll
+                for (int i = 0; i < DV; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+                static_for<NB>([&](auto kbc) {
+                    constexpr int kb = decltype(kbc)::value;
+                    float pv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 d = f32x2{s[kb][r], s[kb][r + 1]} - f32x2{m, m};        // v_pk_add_f32
+                        pv[r] = __builtin_amdgcn_exp2f(d.x);
+                        pv[r + 1] = __builtin_amdgcn_exp2f(d.y);
+                    }
+                    const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
+                    // row sum of the ROUNDED weights (the ones the PV product uses): eight dot2's instead of sixteen adds
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        l = dot2_acc<T>(pf[c].x, Elem<T>::ones2, l);
+                        l = dot2_acc<T>(pf[c].y, Elem<T>::ones2, l);
+                        l = dot2_acc<T>(pf[c].z, Elem<T>::ones2, l);
+                        l = dot2_acc<T>(pf[c].w, Elem<T>::ones2, l);
+                    }
+                    static_for<2>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr (kb * 2 + c < NCH) {         // (a chunk of nothing but padding is skipped)
+#pragma unroll
+                            for (int dvb = 0; dvb < DV; ++dvb) {
+                                const T* src = v_lds + vfrag + (kbase + kb * 32 + 16 * c) * VP + dvb * 32;
+                                const u32x2 w0 = lds_read_tr16(src), w1 = lds_read_tr16(src + 8 * VP);
+                                uint4 a;
+                                a.x = w0.x; a.y = w0.y; a.z = w1.x; a.w = w1.y;
+                                o[dvb] = Elem<T>::mfma32(a, pf[c], o[dvb]);
+                            }
+                        }
+                    });
+                });
+                const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, l), __builtin_bit_cast(uint32_t, l), false, false);
+                return __builtin_bit_cast(float, e.x) + __builtin_bit_cast(float, e.y);
+            };
+            {
+                const float l1 = run(std::integral_constant<int, NB1>{}, std::integral_constant<int, NCH1>{}, 0, cmask1);
+                const float inv1 = p.out_scale / l1;
+#pragma unroll
+                for (int i = 0; i < DV; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 t = f32x2{o[i][r], o[i][r + 1]} * f32x2{inv1, inv1};
+                        osum[i][r] = t.x;
+                        osum[i][r + 1] = t.y;
+                    }
+                const float l2 = run(std::integral_constant<int, NB2>{}, std::integral_constant<int, 2 * NB2>{}, 32 * NB1, cmask2);
+                inv2 = p.out_scale2 / l2;
+            }
+
+            // ---- out = osum + o * inv2.  Lane (query col, hi) holds channels 32 dvb + 8 g + 4 hi .. + 3 (8 bytes).
+            T* ob = (T*)p.out + (long)qb_img * p.o_bs + (long)qrow * p.o_rs + h * D;
+#pragma unroll
+            for (int dvb = 0; dvb < DV; ++dvb) {
+                uint2 w[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x2 i2 = {inv2, inv2};
+                    const f32x2 f01 = f32x2{o[dvb][4 * g], o[dvb][4 * g + 1]} * i2 + f32x2{osum[dvb][4 * g], osum[dvb][4 * g + 1]};
+                    const f32x2 f23 = f32x2{o[dvb][4 * g + 2], o[dvb][4 * g + 3]} * i2 + f32x2{osum[dvb][4 * g + 2], osum[dvb][4 * g + 3]};
+                    w[g].x = pack2<T>(f01.x, f01.y);
+                    w[g].y = pack2<T>(f23.x, f23.y);
+                }
+                if constexpr (WIDE) {
+                    // groups (g, g + 1): the hi = 0 lanes hand their 8 bytes of group g + 1 to the partner lane and receive its
+                    // 8 bytes of group g (v_permlane32_swap: rows 2-3 of the first operand <-> rows 0-1 of the second) -- every
+                    // lane then owns the 16 contiguous bytes of channels 8 (g + hi) .. + 7
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        const u32x2 sx = __builtin_amdgcn_permlane32_swap(w[g].x, w[g + 1].x, false, false);
+                        const u32x2 sy = __builtin_amdgcn_permlane32_swap(w[g].y, w[g + 1].y, false, false);
+                        const uint4 piece = {sx.x, sy.x, sx.y, sy.y};
+                        *(uint4*)(ob + dvb * 32 + 8 * (g + hi)) = piece;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(uint2*)(ob + dvb * 32 + 8 * g + 4 * hi) = w[g];
+                }
+            }
+#pragma unroll
+            for (int dc = 0; dc < DC; ++dc) qf[dc] = qn[dc];
+            qrow = nrow;
+            qb_img = nimg;
+        }
+        j = seg_end;
+    }
+}
+
 template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
@@ -523,6 +766,7 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
             else if (knob(KNOB_ATTN_HL) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);      // A/B: mask rows through the wave's LDS patch (measured 6 % slower: the divergent fragment loads are not the limiter)
+            else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, false, true>), grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
@@ -534,7 +778,9 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     }
     if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
     else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
+    else if (qb == 1 && knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
     else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+    else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
@@ -545,6 +791,37 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
     if (p.k2) {
         if constexpr (D == 64) {
             AttnParams q = p;
+            // both sets resident in LDS (knob attn_x: 1 = default, 2 = the same with 8-byte stores, 0 = the generic two-pass kernel)
+            const int xk = knob(KNOB_ATTN_X);
+            if (xk && q.Nk > 64 && q.Nk <= 96 && q.Nk2 > 32 && q.Nk2 <= 64 && (q.o_rs % 8) == 0 && (q.o_bs % 8) == 0 &&
+                ((uintptr_t)q.out % 16) == 0 && q.B % q.kv_group == 0 && q.Nq % 32 == 0) {
+                q.x_nqb = (q.Nq + 31) / 32;
+                q.x_bpp = q.kv_group * q.x_nqb;
+                q.x_total = (long)(q.B / q.kv_group) * q.H * q.x_bpp;
+                // up to 48 query blocks (12 per wave) per workgroup -- the pair's 36 KB of K / V are then staged for 384 KB of Q / O,
+                // with enough workgroups left for the dispatcher to level the tail -- and no fewer than 8 on small problems, which
+                // would otherwise leave CUs idle (K / V come from the L2 there)
+                long per = q.x_total / 1024;
+                per = per < 8 ? 8 : (per > 48 ? 48 : per);
+                long g = (q.x_total + per - 1) / per;
+                if (g < 1) g = 1;
+                if (g > 0x7fffffffL) {
+                    im360_set_error("attn_fwd2: %ld workgroups exceed the grid limit", g);
+                    return IM360_ERR_ARG;
+                }
+                dim3 xgrid((unsigned)g, 1, 1);
+                // the model's shape (77 + 64 keys: five real 16-key chunks, second set unmasked) or the general instance
+                const bool model_shape = q.Nk <= 80 && q.Nk2 == 64;
+                if (xk == 2) {
+                    if (model_shape) hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 5, 2, false, false>), xgrid, dim3(256), 0, stream, q);
+                    else hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 6, 2, true, false>), xgrid, dim3(256), 0, stream, q);
+                } else {
+                    if (model_shape) hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 5, 2, false, true>), xgrid, dim3(256), 0, stream, q);
+                    else hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 6, 2, true, true>), xgrid, dim3(256), 0, stream, q);
+                }
+                IM360_CHECK_LAUNCH();
+                return IM360_OK;
+            }
             const int nw = q.Nq <= 32 ? 1 : (q.Nq <= 64 ? 2 : 4);
             q.nqt = (q.Nq + 32 * nw - 1) / (32 * nw);
             const long nblk = (long)q.B * q.H * q.nqt;
@@ -604,6 +881,7 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;
     p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = accumulate; p.bias_packed = bias_packed;
     p.k2 = nullptr; p.v2 = nullptr; p.Nk2 = 0; p.k2_bs = p.k2_rs = p.v2_bs = p.v2_rs = 0; p.out_scale2 = 0.f;
+    p.x_nqb = p.x_bpp = 0; p.x_total = 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, stream);
     if (dtype == 0) return D == 64 ? launch_attn<__bf16, 64>(p, s) : launch_attn<__bf16, 32>(p, s);
@@ -637,6 +915,7 @@ extern "C" int im360_attn_fwd2(const void* q, const void* k, const void* v, cons
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = 0;
     p.scale_log2 = scale * LOG2E; p.out_scale = out_scale; p.accumulate = 0; p.bias_packed = 0;
     p.k2 = k2; p.v2 = v2; p.Nk2 = (int)Nk2; p.k2_bs = k2_bs; p.k2_rs = k2_rs; p.v2_bs = v2_bs; p.v2_rs = v2_rs; p.out_scale2 = out_scale2;
+    p.x_nqb = p.x_bpp = 0; p.x_total = 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_ATTN, stream);
     if (dtype == 0) return launch_attn<__bf16, 64>(p, s);

@@ -47,7 +47,9 @@ int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, 
 /* Two key / value sets for the same queries in one launch (head dim 64, no bias):
  *   out = out_scale * softmax(q k^T scale) v + out_scale2 * softmax(q k2^T scale) v2
  * -- the text tokens and the IP-adapter tokens of the spatial cross attention, which the reference evaluates as two
- * attention calls and an add.  Strides / kv_group as in im360_attn_fwd.
+ * attention calls and an add.  Strides / kv_group as in im360_attn_fwd.  With 65..96 + 33..64 keys, Nq % 32 == 0 and 16-byte
+ * aligned output rows (the model's 77 + 64 tokens) the launch keeps BOTH sets resident in LDS per (video, head) and streams the
+ * query blocks of all the video's frames past them (knob 11); other shapes take the generic two-pass kernel.
  * Replaces: IPCrossAttention.forward, animatediff/models/attention.py:113-148. */
 int im360_attn_fwd2(const void* q, const void* k, const void* v, const void* k2, const void* v2, void* out,
                     int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Nk2, int64_t D,
@@ -249,7 +251,8 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring kernel for convolutions too; 5 reserved; 6 ablation bits of the
  * ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions; 8 taps-innermost K order of the 3x3 convolutions
  * (default 1); 9 packed-rows LayerNorm at 320 channels (default 1); 10 cout groups of the persistent kernel's tile walk:
- * 0 = by weight size, 2 / 4 / 8 forced).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * 0 = by weight size, 2 / 4 / 8 forced; 11 text + IP cross attention: 1 (default) key / value sets resident in LDS, 2 the same
+ * with 8-byte output stores, 0 the generic two-pass kernel).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
  * change the fp32 summation order, 6 breaks results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);
 

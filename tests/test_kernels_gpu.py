@@ -86,20 +86,49 @@ def test_attention_two_kv_sets_accumulate(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,Nq,group", [(4, 300, 2), (2, 1024, 1), (6, 40, 3)])
+@pytest.mark.parametrize("B,Nq,group", [(4, 300, 2), (2, 1024, 1), (6, 40, 3), (32, 64, 16), (4, 1056, 2)])
 def test_attention_two_kv_sets_one_launch(dt, B, Nq, group):
     """im360_attn_fwd2: text (77 keys, ragged tile) + IP (64 keys) cross attention of one query in one launch, with the
-    per-video key / value sharing (kv_group) and an IP scale, against the oracle's two attention calls."""
+    per-video key / value sharing (kv_group) and an IP scale, against the oracle's two attention calls.  Nq % 32 == 0 runs
+    the resident-K/V kernel (both store forms, bit-identical), the other shapes the generic two-pass kernel; knob attn_x = 0
+    forces the generic kernel everywhere."""
     H, D = 5, 64
     C = H * D
     q = q16(rnd(B, Nq, C, seed=70, scale=0.3), dt)
     k1, v1, k2, v2 = (q16(rnd(B // group, n, C, seed=s), dt) for n, s in ((77, 71), (77, 72), (64, 73), (64, 74)))
     rep = lambda t: t.repeat_interleave(group, 0)
-    for scale, s2 in ((1.0, 1.0), (D ** -0.5, 0.7)):
-        ref = OU.sdpa(q, rep(k1), rep(v1), H, scale=scale) + s2 * OU.sdpa(q, rep(k2), rep(v2), H, scale=scale)
-        out = K.attention2(q.to(dt).cuda(), k1.to(dt).cuda(), v1.to(dt).cuda(), k2.to(dt).cuda(), v2.to(dt).cuda(), H,
-                           scale=scale, out_scale2=s2, kv_group=group)
-        assert rel(out, ref) < 1.5 * TOL[dt]
+    dq, dk1, dv1, dk2, dv2 = (t.to(dt).cuda() for t in (q, k1, v1, k2, v2))
+    try:
+        for scale, s2 in ((1.0, 1.0), (D ** -0.5, 0.7)):
+            ref = OU.sdpa(q, rep(k1), rep(v1), H, scale=scale) + s2 * OU.sdpa(q, rep(k2), rep(v2), H, scale=scale)
+            outs = []
+            for x in (1, 2, 0):
+                K.tuning_set("attn_x", x)
+                out = K.attention2(dq, dk1, dv1, dk2, dv2, H, scale=scale, out_scale2=s2, kv_group=group)
+                assert rel(out, ref) < 1.5 * TOL[dt] and blockrel(out, ref, 32) < 3 * TOL[dt], (x, scale)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1])          # 16-byte and 8-byte stores of the same values
+    finally:
+        K.tuning_set("attn_x", 1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("n1,n2", [(90, 48), (96, 64), (65, 33), (80, 64)])
+def test_attention_resident_kv_sets_general_key_counts(dt, n1, n2):
+    """The resident-K/V cross attention away from the model's 77 + 64 keys: both sets ragged (masked by the MFMA C operand),
+    exactly full blocks, the smallest counts it accepts; strided (fused-projection) query rows; a workgroup range that
+    crosses (video, head) pairs (3 videos x 2 frames x 10 blocks x 4 heads = 240 blocks over 5 workgroups)."""
+    B, H, D, Nq, group = 6, 4, 64, 320, 2
+    C = H * D
+    qw = q16(rnd(B, Nq, 2 * C, seed=75, scale=0.3), dt)
+    k1, v1, k2, v2 = (q16(rnd(B // group, n, C, seed=s), dt) for n, s in ((n1, 76), (n1, 77), (n2, 78), (n2, 79)))
+    rep = lambda t: t.repeat_interleave(group, 0)
+    q = qw[..., C:]
+    ref = OU.sdpa(q, rep(k1), rep(v1), H) + 0.5 * OU.sdpa(q, rep(k2), rep(v2), H)
+    out = K.attention2(qw.to(dt).cuda()[..., C:], k1.to(dt).cuda(), v1.to(dt).cuda(), k2.to(dt).cuda(), v2.to(dt).cuda(), H,
+                       out_scale2=0.5, kv_group=group)
+    assert rel(out, ref) < 1.5 * TOL[dt] and blockrel(out, ref, 32) < 3 * TOL[dt]
+    assert (out.float().cpu() - ref).abs().max() < 0.05
 
 
 def test_softmax_rows_and_single_head_attention():
@@ -171,6 +200,32 @@ def test_attention_packed_bias_through_the_matrix_pipe(dt, B, H, Nq, Nk):
     with pytest.raises(RuntimeError, match="head dim 32"):
         x = torch.zeros(1, 64, 128, dtype=dt, device="cuda")
         K.attention(x, x, x, 2, bias=torch.zeros(64, 64, dtype=torch.float16, device="cuda"), bias_packed=True)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_attention_dot_sum_variant(dt):
+    """Knob attn_ds: row sums as dot2's over the packed (rounded) weights and the half-wave max exchange through
+    v_permlane32_swap, on the four-wave kernels: d = 64 (one / two query blocks per wave, ragged keys, a spiked key that moves
+    the running max late) and d = 32 with the packed bias -- against the oracle and close to the plain variant."""
+    g = torch.Generator().manual_seed(87)
+    try:
+        for H, D, Nq, Nk, has_bias, qb in ((2, 64, 512, 200, False, 1), (2, 64, 512, 1096, False, 2), (4, 32, 600, 328, True, 2), (4, 32, 256, 640, True, 1)):
+            q, k, v = (q16(torch.randn(2, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
+            k[:, Nk - 7] *= 6.0
+            k = q16(k, dt)
+            bias = q16(torch.rand(Nq, Nk, generator=g) * 2 - 1, dt) if has_bias else None
+            db = None if bias is None else K.pack_attn_bias(bias.to(dt).cuda())
+            ref = OU.sdpa(q, k, v, H, bias=bias)
+            K.tuning_set("attn_qb", qb)
+            outs = []
+            for ds in (0, 1):
+                K.tuning_set("attn_ds", ds)
+                outs.append(K.attention(q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda(), H, bias=db, bias_packed=has_bias))
+                assert rel(outs[-1], ref) < TOL[dt] and blockrel(outs[-1], ref, 32) < 2 * TOL[dt], (D, qb, ds)
+            assert rel(outs[1], outs[0].float().cpu()) < TOL[dt]
+    finally:
+        K.tuning_set("attn_qb", 0)
+        K.tuning_set("attn_ds", 0)
 
 
 def test_attention_softmax_rescale_branch():

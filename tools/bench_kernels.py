@@ -298,6 +298,48 @@ def bench_lnfold(iters):
     K.tuning_set("ring_groups", 0)
 
 
+def bench_attn_ds(iters):
+    """Knob attn_ds (row sums as dot2's of the packed weights, half-wave exchange through v_permlane32_swap) on the step's
+    self-attention and WarpAttn shapes: plain vs DS."""
+    shapes = [("pano L0 self", 32, 5, 8192, 8192, 64, False), ("pers L0 self", 640, 5, 1024, 1024, 64, False),
+              ("pano L1 self", 32, 10, 2048, 2048, 64, False), ("pers L1 self", 640, 10, 256, 256, 64, False),
+              ("pano L2 self", 32, 20, 512, 512, 64, False), ("pers L2 self", 640, 20, 64, 64, 64, False),
+              ("warp L0 e2p", 32, 5, 8192, 20480, 32, True), ("warp L1 e2p", 32, 10, 2048, 5120, 32, True),
+              ("warp L1 p2e", 32, 10, 5120, 2048, 32, True), ("warp L2 e2p", 32, 20, 512, 1280, 32, True)]
+    for name, B, H, Nq, Nk, D, bias in shapes:
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        bb = K.pack_attn_bias((torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT)) if bias else None
+        fl = 4.0 * B * H * Nq * Nk * D
+        row = []
+        for ds in (0, 1, 0, 1):
+            K.tuning_set("attn_ds", ds)
+            t = timeit(lambda: K.attention(q, k, v, H, bias=bb, bias_packed=bias), iters)
+            row.append(f"ds={ds}: {t * 1e3:7.3f} ms {fl / t / 2.5e15 * 100:4.1f}%")
+        K.tuning_set("attn_ds", 0)
+        print(f"attn_ds {name:14s} " + " | ".join(row))
+
+
+def bench_xattn(iters):
+    """Text + IP cross attention (77 + 64 keys, one context per 16-frame video): generic two-pass kernel (knob attn_x 0) vs
+    both key / value sets resident in LDS (1: 16-byte stores, 2: 8-byte stores).  Floor = Q read + O written at HBM speed."""
+    for name, B, H, Nq, grp in [("pers L0", 640, 5, 1024, 16), ("pano L0", 32, 5, 8192, 16), ("pers L1", 640, 10, 256, 16),
+                                ("pano L1", 32, 10, 2048, 16), ("pers L2", 640, 20, 64, 16), ("pano L2", 32, 20, 512, 16)]:
+        D = 64
+        q = rn(B, Nq, H * D)
+        k1, v1, k2, v2 = rn(B // grp, 77, H * D), rn(B // grp, 77, H * D), rn(B // grp, 64, H * D), rn(B // grp, 64, H * D)
+        fl = 4.0 * B * H * Nq * 141 * D
+        by = 2.0 * 2 * B * Nq * H * D
+        row, outs = [], []
+        for x in (0, 1, 2):
+            K.tuning_set("attn_x", x)
+            t = timeit(lambda: K.attention2(q, k1, v1, k2, v2, H, kv_group=grp), iters)
+            outs.append(K.attention2(q, k1, v1, k2, v2, H, kv_group=grp).float())
+            row.append(f"attn_x={x}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s {by / t / 1e9:6.0f} GB/s")
+        K.tuning_set("attn_x", 1)
+        d = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
+        print(f"xattn {name:8s} M={B * Nq:7d} H={H:2d}: " + " | ".join(row) + f" | rel diff vs generic {d:.2e}, wide == narrow stores: {bool((outs[1] == outs[2]).all())}")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     iters = 10
