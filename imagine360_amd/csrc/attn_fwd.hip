@@ -66,8 +66,12 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // DS ("dot sums", knob attn_ds): the row sums are taken over the ROUNDED weights -- the packed P words the PV product uses -- with
 // eight v_dot2c against (1, 1) per 16 scores instead of sixteen v_add, and the two half-waves exchange their maxima through
 // v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip whose lgkmcnt wait also drains the prefetched fragments).
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(AttnParams p) {
+// ONE (Nk <= 64: a single K / V tile, levels 2 / 3 of the perspective branch): one LDS buffer instead of two and three waves per
+// SIMD -- these launches are thousands of tiny workgroups whose only lever is how many of them a CU holds (43 KB of LDS each
+// allowed three).
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3 : 2, ONE ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
+    static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
     constexpr int NT = NW * 64;
@@ -84,8 +88,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int KT = KVB * KP, VT = KVB * VP;  // tile sizes (elements)
 
     // double-buffered K / V tiles: one barrier per KV tile (the next tile is written while this one is consumed)
-    __shared__ __attribute__((aligned(16))) T k_lds2[2 * KT];
-    __shared__ __attribute__((aligned(16))) T v_lds2[2 * VT];
+    __shared__ __attribute__((aligned(16))) T k_lds2[(ONE ? 1 : 2) * KT];
+    __shared__ __attribute__((aligned(16))) T v_lds2[(ONE ? 1 : 2) * VT];
     constexpr bool BF_LDS = BF && QB > 1 && BL;
     constexpr int BROWS = 32 * QB;             // mask rows of one wave
     constexpr int BLD = BROWS * 4 / 64;        // 16-byte loads per lane and 32-key half (4 lanes per 64-byte row segment)
@@ -341,9 +345,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int r = (kb == K0 ? 1 : 0); r < 16; ++r) mloc = fmaxf(mloc, s[qb][kb][r]);
             if constexpr (DS) {
-                // own and partner value in either order (max is symmetric)
-                const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, mloc), __builtin_bit_cast(uint32_t, mloc), false, false);
-                mloc = fmaxf(__builtin_bit_cast(float, e.x), __builtin_bit_cast(float, e.y));
+                float ma, mb;
+                half_wave_pair(mloc, ma, mb);
+                mloc = fmaxf(ma, mb);
             } else {
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
             }
@@ -534,12 +538,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // packed P), and the output stored as whole 16-byte pieces (the two half-waves trade half of their 8-byte fragments through
 // v_permlane32_swap).  Work is dealt as contiguous ranges of the (pair, frame, query block) sequence, so a workgroup
 // re-stages only when its range crosses into the next pair.  What is left is the HBM time of Q and O.
-template <typename T, int NB1, int NCH1, int NB2, bool RAG2, bool WIDE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 3, RAG2 ? 2 : 3))) void xattn_resident_kernel(AttnParams p) {
+// QDMA (NWV = 12 waves, one workgroup per CU): the register prefetch above keeps ONE 4 KB block per wave in flight (48 KB per CU:
+// 3.0 TB/s of Q + O traffic measured, latency-bound) and fetches 32-byte row segments (32 cache lines per instruction).  Here
+// each wave owns a two-slot LDS ring (8 KB) that global_load_lds fills two blocks ahead with whole 128-byte rows (8 rows per
+// instruction), no registers involved; the lane -> source mapping applies the XOR swizzle ((row >> 1) & 7 on the 16-byte
+// chunk index) that makes the fragment-order ds_read_b128 of a block conflict-free.  The asm LDS-DMA is invisible to hipcc's
+// vmcnt bookkeeping, so the loop issues the same VMEM sequence every iteration (4 DMA pieces, clamped to the wave's last block,
+// then 4 stores) and waits with hand-counted immediates; vmcnt(0) before the wave ends (a DMA landing after the workgroup's
+// LDS has been handed to another one would corrupt it).
+template <typename T, int NB1, int NCH1, int NB2, bool RAG2, bool WIDE, int NWV = 4, bool QDMA = false>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(RAG2 && !QDMA ? 2 : 3, RAG2 && !QDMA ? 2 : 3))) void xattn_resident_kernel(AttnParams p) {
+    static_assert(!QDMA || NWV == 12, "the ring variant is sized for twelve waves");
+    constexpr int NTH = NWV * 64;
     constexpr int D = 64, KP = D + 8, VP = 96, DC = D / 16, DV = D / 32;
     constexpr int NKR = 32 * (NB1 + NB2);          // key rows held (set 2 starts at row 32 NB1)
-    __shared__ __attribute__((aligned(16))) T k_lds[NKR * KP];
-    __shared__ __attribute__((aligned(16))) T v_lds[NKR * VP];
+    constexpr int KBYTES = NKR * KP * 2, VBYTES = NKR * VP * 2, QSLOT = 32 * D * 2;       // one query block = 4 KB
+    __shared__ __attribute__((aligned(16))) char lds_all[KBYTES + VBYTES + (QDMA ? NWV * 2 * QSLOT : 0)];
+    T* const k_lds = (T*)lds_all;
+    T* const v_lds = (T*)(lds_all + KBYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 
         const int bk = (int)(pair / p.H), h = (int)(pair % p.H);
         // ---- stage this pair's K (scaled) and V, both sets; rows past a set's keys are zeros
         __syncthreads();                     // every wave is done with the previous pair
-        for (int c = tid; c < NKR * (D / 8); c += 256) {
+        for (int c = tid; c < NKR * (D / 8); c += NTH) {
             const int row = c / (D / 8), c8 = c % (D / 8);
             const bool second = row >= 32 * NB1;
             const int kr = second ? row - 32 * NB1 : row;
@@ -598,25 +614,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 
         int g_cur = (int)((jj - base) / p.x_nqb), qblk_cur = (int)((jj - base) % p.x_nqb);
         uint4 qf[DC], qn[DC];
         int qrow = 0, qb_img = 0;
-        if (jj < seg_end) {
-            const T* qs = q_src(g_cur, qblk_cur, qrow, qb_img);
+        auto advance = [&](int n) {          // (g_cur, qblk_cur) n blocks on
+            qblk_cur += n;
+            while (qblk_cur >= p.x_nqb) {
+                qblk_cur -= p.x_nqb;
+                ++g_cur;
+            }
+        };
+        // ---- QDMA: the wave's ring and its request stream (runs two blocks ahead of the compute position)
+        const uint32_t ring = QDMA ? __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_all) + KBYTES + VBYTES + wid_s * (2 * QSLOT) : 0u;
+        const char* ring_p = lds_all + KBYTES + VBYTES + wid_s * (2 * QSLOT);
+        const int frag_off = col * (D * 2);                          // row of this lane's fragments; + ((2 dc + hi) ^ ((col >> 1) & 7)) * 16
+        const int fsw = (col >> 1) & 7;
+        int g_req = g_cur, qblk_req = qblk_cur;                      // the block requested next
+        long jj_req = jj;
+        auto request = [&](int slot) {
+            // piece i: lanes -> rows 8 i + lane / 8, LDS chunk position lane % 8 holding data chunk (lane % 8) ^ ((row >> 1) & 7)
+            const T* qb = (const T*)p.q + (long)(bk * p.kv_group + g_req) * p.q_bs + (long)(qblk_req * 32) * p.q_rs + h * D;
 #pragma unroll
-            for (int dc = 0; dc < DC; ++dc) qf[dc] = *(const uint4*)(qs + dc * 16);
-        }
-        for (; jj < seg_end; jj += 4) {
-            // the next block's Q (the wave's last block re-requests itself: always-executed loads keep hipcc's waits counted)
-            int nrow, nimg;
-            if (jj + 4 < seg_end) {
-                qblk_cur += 4;
-                while (qblk_cur >= p.x_nqb) {
-                    qblk_cur -= p.x_nqb;
-                    ++g_cur;
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + (lane >> 3);
+                const int ch = (lane & 7) ^ ((row >> 1) & 7);
+                lds_dma16_asm(qb + (long)row * p.q_rs + ch * 8, ring + slot * QSLOT + i * 1024);
+            }
+            if (jj_req + NWV < seg_end) {        // (past the wave's last block the same block is requested again: uniform VMEM sequence)
+                jj_req += NWV;
+                qblk_req += NWV;
+                while (qblk_req >= p.x_nqb) {
+                    qblk_req -= p.x_nqb;
+                    ++g_req;
                 }
             }
+        };
+        int it = 0;
+        if constexpr (QDMA) {
+            if (jj < seg_end) {
+                request(0);
+                request(1);
+            }
+        } else {
+            if (jj < seg_end) {
+                const T* qs = q_src(g_cur, qblk_cur, qrow, qb_img);
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc) qf[dc] = *(const uint4*)(qs + dc * 16);
+            }
+        }
+        for (; jj < seg_end; jj += NWV, ++it) {
+            int nrow = 0, nimg = 0;
+            if constexpr (QDMA) {
+                // block `it` of this wave sits in slot it & 1: queue behind it = [the next block's 4 pieces] (+ 4 stores from the
+                // second iteration on; the stores of two iterations back are then required too -- long done)
+                if (it == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                const char* sl = ring_p + (it & 1) * QSLOT + frag_off;
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc) qf[dc] = *(const uint4*)(sl + (((2 * dc + hi) ^ fsw) << 4));
+                qrow = qblk_cur * 32 + col;
+                qb_img = bk * p.kv_group + g_cur;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the slot can be refilled
+                request(it & 1);
+                if (jj + NWV < seg_end) advance(NWV);
+            } else {
+            // the next block's Q (the wave's last block re-requests itself: always-executed loads keep hipcc's waits counted)
+            if (jj + NWV < seg_end) advance(NWV);
             const T* qs = q_src(g_cur, qblk_cur, nrow, nimg);
 #pragma unroll
             for (int dc = 0; dc < DC; ++dc) qn[dc] = *(const uint4*)(qs + dc * 16);
             __builtin_amdgcn_sched_barrier(0);          // (hipcc sinks the requests to the middle of the block otherwise)
+            }
 
             f32x16 osum[DV];
             float inv2 = 0.f;
@@ -644,9 +709,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 
 #pragma unroll
                     for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) m = fmaxf(m, s[kb][r]);
                 {
-                    // both halves of the wave (keys 4 hi + ...): own and partner value in either order -- max is symmetric
-                    const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, m), __builtin_bit_cast(uint32_t, m), false, false);
-                    m = fmaxf(__builtin_bit_cast(float, e.x), __builtin_bit_cast(float, e.y));
+                    float ma, mb;               // both halves of the wave (keys 4 hi + ...)
+                    half_wave_pair(m, ma, mb);
+                    m = fmaxf(ma, mb);
                 }
                 float l = 0.f;
 #pragma unroll
@@ -685,8 +750,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 
                         }
                     });
                 });
-                const u32x2 e = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, l), __builtin_bit_cast(uint32_t, l), false, false);
-                return __builtin_bit_cast(float, e.x) + __builtin_bit_cast(float, e.y);
+                float la, lb;
+                half_wave_pair(l, la, lb);
+                return la + lb;
             };
             {
                 const float l1 = run(std::integral_constant<int, NB1>{}, std::integral_constant<int, NCH1>{}, 0, cmask1);
@@ -733,13 +799,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAG2 ? 2 : 
                         *(uint2*)(ob + dvb * 32 + 8 * g + 4 * hi) = w[g];
                 }
             }
+            if constexpr (!QDMA) {
 #pragma unroll
-            for (int dc = 0; dc < DC; ++dc) qf[dc] = qn[dc];
-            qrow = nrow;
-            qb_img = nimg;
+                for (int dc = 0; dc < DC; ++dc) qf[dc] = qn[dc];
+                qrow = nrow;
+                qb_img = nimg;
+            }
         }
         j = seg_end;
     }
+    if constexpr (QDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <typename T, int D, bool HAS_BIAS>
@@ -776,6 +845,15 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
         im360_set_error("attn_fwd: packed bias matrices are supported for head dim 32 only");
         return IM360_ERR_UNSUPPORTED;
     }
+    if constexpr (!HAS_BIAS && D == 64) {
+        if (p.Nk <= KVB && qb == 1 && knob(KNOB_ATTN_ONE)) {
+            if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, false, false, false, false, false, true>), grid, dim3(64), 0, stream, p);
+            else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, false, false, false, false, false, true>), grid, dim3(128), 0, stream, p);
+            else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, false, false, false, false, false, true>), grid, dim3(256), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
     if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
     else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
     else if (qb == 1 && knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
@@ -798,21 +876,35 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
                 q.x_nqb = (q.Nq + 31) / 32;
                 q.x_bpp = q.kv_group * q.x_nqb;
                 q.x_total = (long)(q.B / q.kv_group) * q.H * q.x_bpp;
-                // up to 48 query blocks (12 per wave) per workgroup -- the pair's 36 KB of K / V are then staged for 384 KB of Q / O,
-                // with enough workgroups left for the dispatcher to level the tail -- and no fewer than 8 on small problems, which
-                // would otherwise leave CUs idle (K / V come from the L2 there)
+                // the model's shape (77 + 64 keys: five real 16-key chunks, second set unmasked) or the general instance
+                const bool model_shape = q.Nk <= 80 && q.Nk2 == 64;
+                // knob 3: twelve-wave workgroups (one per CU) whose waves fetch their query blocks through private LDS rings
+                // (global_load_lds, two blocks ahead); needs 16-byte aligned query rows
+                const bool ring = xk == 3 && model_shape && (q.q_rs % 8) == 0 && (q.q_bs % 8) == 0 && ((uintptr_t)q.q % 16) == 0 && q.x_total >= 12 * 256;
+                // up to 48 query blocks (12 per wave) per four-wave workgroup -- the pair's 36 KB of K / V are then staged for 384 KB
+                // of Q / O, with enough workgroups left for the dispatcher to level the tail -- and no fewer than 8 on small problems,
+                // which would otherwise leave CUs idle (K / V come from the L2 there); the ring variant: 12 blocks per wave likewise
                 long per = q.x_total / 1024;
                 per = per < 8 ? 8 : (per > 48 ? 48 : per);
                 long g = (q.x_total + per - 1) / per;
+                if (ring) {
+                    // one workgroup per CU: a whole number of rounds of <= 144 blocks (12 per wave) each
+                    static const int ncu = [] {
+                        int dev = 0, n = 0;
+                        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+                        return n > 0 ? n : 256;
+                    }();
+                    g = (long)ncu * ((q.x_total + 144L * ncu - 1) / (144L * ncu));
+                }
                 if (g < 1) g = 1;
                 if (g > 0x7fffffffL) {
                     im360_set_error("attn_fwd2: %ld workgroups exceed the grid limit", g);
                     return IM360_ERR_ARG;
                 }
                 dim3 xgrid((unsigned)g, 1, 1);
-                // the model's shape (77 + 64 keys: five real 16-key chunks, second set unmasked) or the general instance
-                const bool model_shape = q.Nk <= 80 && q.Nk2 == 64;
-                if (xk == 2) {
+                if (ring) {
+                    hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 5, 2, false, true, 12, true>), xgrid, dim3(768), 0, stream, q);
+                } else if (xk == 2) {
                     if (model_shape) hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 5, 2, false, false>), xgrid, dim3(256), 0, stream, q);
                     else hipLaunchKernelGGL((xattn_resident_kernel<T, 3, 6, 2, true, false>), xgrid, dim3(256), 0, stream, q);
                 } else {

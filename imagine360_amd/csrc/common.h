@@ -77,6 +77,20 @@ template <> __device__ __forceinline__ float dot2_acc<_Float16>(uint32_t a, uint
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
 }
 
+// The value of this lane and of its partner in the other half-wave (lane ^ 32), in unspecified order -- for symmetric
+// reductions (max, sum) across the two halves.  One v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip whose
+// lgkmcnt wait also drains every prefetched fragment read).  The swap exchanges lanes 32-63 of its first operand with lanes
+// 0-31 of the second; fed the same value twice it leaves (x[lane & 31], x[32 + (lane & 31)]).  Issued from inline asm:
+// hipcc (ROCm 7.2) drops the SECOND result of __builtin_amdgcn_permlane32_swap when both operands are copies of one value
+// (seen in the ISA: max(e.x, e.y) became e.x), also through an opaque copy.  s_nop 1 = the two wait states the hardware
+// needs between a VALU write of an operand and the swap.
+__device__ __forceinline__ void half_wave_pair(float x, float& a, float& b) {
+    uint32_t u = __builtin_bit_cast(uint32_t, x), v = u;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+    a = __builtin_bit_cast(float, u);
+    b = __builtin_bit_cast(float, v);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 
@@ -140,6 +154,20 @@ __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
     const f32x2 e = {__builtin_amdgcn_exp2f(w.x), __builtin_amdgcn_exp2f(w.y)};
     const f32x2 erf_abs = 1.0f - q * e;                           // erf(|x| / sqrt 2)
     return (ax * 0.5f) * erf_abs + x * 0.5f;                      // x/2 * (1 + sign(x) erf(|x| / sqrt 2))
+}
+
+// One 16-byte-per-lane LDS-DMA load issued from inline asm: `lds_dst` is the wave-uniform LDS byte address of the KiB the
+// wave fills (lane-linear), `gsrc` each lane's source.  hipcc models the builtin form as a pending LDS access of unknown
+// order, which turns every ds_read wait of the kernel into lgkmcnt(0); hidden in asm, fragment reads get counted waits.
+// The asm loads are absent from hipcc's vmcnt bookkeeping: the kernel waits for them itself (counted vmcnt + barrier),
+// and hidden loads can only make hipcc's own waits stricter (completion is in order).  M0 is compiler-reserved and not
+// preserved around a statement, so it is saved and restored inside.
+__device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
 }
 
 // compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>), for bodies that need the index as

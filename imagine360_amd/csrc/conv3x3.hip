@@ -684,21 +684,6 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     tile_epilogue<T, NT, TM, TN, EPI, false, UP2>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
 
-// One 16-byte-per-lane LDS-DMA load issued from inline asm: `lds_dst` is the wave-uniform LDS byte address of the KiB the
-// wave fills (lane-linear), `gsrc` each lane's source.  hipcc models the builtin form as a pending LDS access of unknown
-// order, which turns every ds_read wait of the kernel into lgkmcnt(0); hidden in asm, fragment reads get counted waits.
-// The asm loads are absent from hipcc's vmcnt bookkeeping: the kernel waits for them itself (counted vmcnt + barrier),
-// and hidden loads can only make hipcc's own waits stricter (completion is in order).  M0 is compiler-reserved and not
-// preserved around a statement, so it is saved and restored inside.
-__device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-
-
 // ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
 // The kernel above keeps two LDS stages of 64 channels and drains the LDS-DMA queue at every step (one barrier per step,
 // vmcnt(0) in front of it): with one workgroup per CU a step lasts as long as its stage takes to arrive (2.7 us measured

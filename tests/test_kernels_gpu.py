@@ -86,7 +86,7 @@ def test_attention_two_kv_sets_accumulate(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,Nq,group", [(4, 300, 2), (2, 1024, 1), (6, 40, 3), (32, 64, 16), (4, 1056, 2)])
+@pytest.mark.parametrize("B,Nq,group", [(4, 300, 2), (2, 1024, 1), (6, 40, 3), (32, 64, 16), (4, 1056, 2), (64, 1024, 16)])
 def test_attention_two_kv_sets_one_launch(dt, B, Nq, group):
     """im360_attn_fwd2: text (77 keys, ragged tile) + IP (64 keys) cross attention of one query in one launch, with the
     per-video key / value sharing (kv_group) and an IP scale, against the oracle's two attention calls.  Nq % 32 == 0 runs
@@ -102,14 +102,15 @@ def test_attention_two_kv_sets_one_launch(dt, B, Nq, group):
         for scale, s2 in ((1.0, 1.0), (D ** -0.5, 0.7)):
             ref = OU.sdpa(q, rep(k1), rep(v1), H, scale=scale) + s2 * OU.sdpa(q, rep(k2), rep(v2), H, scale=scale)
             outs = []
-            for x in (1, 2, 0):
+            for x in (1, 2, 0, 3):          # 3: twelve-wave workgroups with LDS-DMA query rings (large problems; else = 1)
                 K.tuning_set("attn_x", x)
                 out = K.attention2(dq, dk1, dv1, dk2, dv2, H, scale=scale, out_scale2=s2, kv_group=group)
                 assert rel(out, ref) < 1.5 * TOL[dt] and blockrel(out, ref, 32) < 3 * TOL[dt], (x, scale)
                 outs.append(out)
             assert torch.equal(outs[0], outs[1])          # 16-byte and 8-byte stores of the same values
+            assert torch.equal(outs[0], outs[3])          # the same arithmetic on ring-fetched queries
     finally:
-        K.tuning_set("attn_x", 1)
+        K.tuning_set("attn_x", 3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

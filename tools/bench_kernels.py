@@ -319,6 +319,31 @@ def bench_attn_ds(iters):
         print(f"attn_ds {name:14s} " + " | ".join(row))
 
 
+def bench_attn_small(iters):
+    """The step's small attention launches (levels 2 / 3): latency / occupancy bound, far from either roofline."""
+    shapes = [("pers L2 self", 640, 20, 64, 64, 64, False), ("pers L3 self", 640, 20, 16, 16, 64, False),
+              ("pano L2 self", 32, 20, 512, 512, 64, False), ("pano L3 self", 32, 20, 128, 128, 64, False),
+              ("warp L2 e2p", 32, 20, 512, 1280, 32, True), ("warp L2 p2e", 32, 20, 1280, 512, 32, True),
+              ("warp L3 e2p", 32, 40, 128, 320, 32, True), ("warp L3 p2e", 32, 40, 320, 128, 32, True)]
+    for name, B, H, Nq, Nk, D, bias in shapes:
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        bb = K.pack_attn_bias((torch.rand(Nq, Nk, device=DEV) * 2 - 1).to(DT)) if bias else None
+        row = []
+        for one in (0, 1):
+            K.tuning_set("attn_one", one)
+            t = timeit(lambda: K.attention(q, k, v, H, bias=bb, bias_packed=bias), iters)
+            fl = 4.0 * B * H * Nq * Nk * D
+            by = 2.0 * (2 * B * Nq + 2 * B * Nk) * H * D
+            row.append(f"attn_one={one}: {t * 1e3:8.3f} ms  {fl / t / 1e12:7.1f} TF/s  {by / t / 1e9:6.0f} GB/s")
+        K.tuning_set("attn_one", 1)
+        print(f"attn_small {name:14s} B={B:4d} H={H:2d} Nq={Nq:5d} Nk={Nk:5d} d={D}: " + " | ".join(row))
+    for name, B, H, Nq, grp in [("pers L3 cross", 640, 20, 16, 16), ("pano L3 cross", 32, 20, 128, 16)]:
+        q = rn(B, Nq, H * 64)
+        k1, v1, k2, v2 = rn(B // grp, 77, H * 64), rn(B // grp, 77, H * 64), rn(B // grp, 64, H * 64), rn(B // grp, 64, H * 64)
+        t = timeit(lambda: K.attention2(q, k1, v1, k2, v2, H, kv_group=grp), iters)
+        print(f"attn_small {name:14s} B={B:4d} H={H:2d} Nq={Nq:5d}: {t * 1e3:8.3f} ms")
+
+
 def bench_xattn(iters):
     """Text + IP cross attention (77 + 64 keys, one context per 16-frame video): generic two-pass kernel (knob attn_x 0) vs
     both key / value sets resident in LDS (1: 16-byte stores, 2: 8-byte stores).  Floor = Q read + O written at HBM speed."""
@@ -330,14 +355,14 @@ def bench_xattn(iters):
         fl = 4.0 * B * H * Nq * 141 * D
         by = 2.0 * 2 * B * Nq * H * D
         row, outs = [], []
-        for x in (0, 1, 2):
+        for x in (0, 1, 2, 3):
             K.tuning_set("attn_x", x)
             t = timeit(lambda: K.attention2(q, k1, v1, k2, v2, H, kv_group=grp), iters)
             outs.append(K.attention2(q, k1, v1, k2, v2, H, kv_group=grp).float())
             row.append(f"attn_x={x}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.1f} TF/s {by / t / 1e9:6.0f} GB/s")
-        K.tuning_set("attn_x", 1)
+        K.tuning_set("attn_x", 3)
         d = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
-        print(f"xattn {name:8s} M={B * Nq:7d} H={H:2d}: " + " | ".join(row) + f" | rel diff vs generic {d:.2e}, wide == narrow stores: {bool((outs[1] == outs[2]).all())}")
+        print(f"xattn {name:8s} M={B * Nq:7d} H={H:2d}: " + " | ".join(row) + f" | rel diff vs generic {d:.2e}, wide == narrow stores: {bool((outs[1] == outs[2]).all())}, ring == registers: {bool((outs[1] == outs[3]).all())}")
 
 
 if __name__ == "__main__":
