@@ -69,7 +69,8 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // ONE (Nk <= 64: a single K / V tile, levels 2 / 3 of the perspective branch): one LDS buffer instead of two and three waves per
 // SIMD -- these launches are thousands of tiny workgroups whose only lever is how many of them a CU holds (43 KB of LDS each
 // allowed three).
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false>
+// ABL (knob attn_dbg, tools/bench_kernels.py attn_ablate; results are garbage): 1 no exp2, 2 no QK^T MFMAs, 4 no PV MFMAs, 8 no K / V staging.
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3 : 2, ONE ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
     T* const vdst = v_lds2 + srow * VP + sc8 * 8;
 
     auto load_tile = [&](int t) {
+        if constexpr ((ABL & 8) != 0) return;
         // a ragged last tile clamps its rows into range (always-executed loads: a predicated load inside an unrolled
         // loop makes hipcc branch around it and drain vmcnt per load).  Out-of-range keys are masked to -inf in the
         // tile body, so their (finite, duplicated) K/V rows never contribute.
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
         vsrc += v_tile;
     };
     auto store_tile = [&](int buf) {
+        if constexpr ((ABL & 8) != 0) return;
         static_for<CLD>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             *(u32x4*)(kdst + buf * KT + i * RSTEP * KP) = kreg[i];
@@ -302,6 +305,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
         auto qk = [&](auto kbc, auto qbc, auto allc) {
             constexpr int kb = decltype(kbc)::value, q1 = decltype(qbc)::value;
             constexpr bool all = decltype(allc)::value;
+            if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+                for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb) s[qb][kb] = negm[qb];
+                return;
+            }
 #pragma unroll
             for (int dc = 0; dc < DC; ++dc) {
                 const uint4 a = *(const uint4*)(kf + kb * 32 * KP + dc * 16);
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
                 float lsum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+                    pv[r] = (ABL & 1) ? s[qb][kb][r] : __builtin_amdgcn_exp2f(s[qb][kb][r]);
                     if constexpr (!DS) lsum += pv[r];
                 }
                 const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
@@ -397,6 +405,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
                 // order), gathered by two transposing reads; the two 32-channel accumulators alternate
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
+                    if constexpr ((ABL & 4) != 0) {
+                        asm volatile("" ::"v"(pf[c].x), "v"(pf[c].y), "v"(pf[c].z), "v"(pf[c].w));
+                        continue;
+                    }
 #pragma unroll
                     for (int dvb = 0; dvb < DV; ++dvb) {
                         const T* src = vf + (kb * 32 + 16 * c) * VP + dvb * 32;
@@ -729,13 +741,15 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(RAG2 &
                     }
                     const uint4 pf[2] = {pack8<T>(pv), pack8<T>(pv + 8)};
                     // row sum of the ROUNDED weights (the ones the PV product uses): eight dot2's instead of sixteen adds
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        l = dot2_acc<T>(pf[c].x, Elem<T>::ones2, l);
-                        l = dot2_acc<T>(pf[c].y, Elem<T>::ones2, l);
-                        l = dot2_acc<T>(pf[c].z, Elem<T>::ones2, l);
-                        l = dot2_acc<T>(pf[c].w, Elem<T>::ones2, l);
-                    }
+                    static_for<2>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr (kb * 2 + c < NCH) {         // (a chunk of nothing but masked keys adds zeros: its exp2's are dead code)
+                            l = dot2_acc<T>(pf[c].x, Elem<T>::ones2, l);
+                            l = dot2_acc<T>(pf[c].y, Elem<T>::ones2, l);
+                            l = dot2_acc<T>(pf[c].z, Elem<T>::ones2, l);
+                            l = dot2_acc<T>(pf[c].w, Elem<T>::ones2, l);
+                        }
+                    });
                     static_for<2>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
                         if constexpr (kb * 2 + c < NCH) {         // (a chunk of nothing but padding is skipped)
@@ -858,6 +872,19 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
     else if (qb == 1 && knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
     else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+    else if (!HAS_BIAS && D == 64 && knob(KNOB_ATTN_DBG)) {
+        if constexpr (!HAS_BIAS && D == 64) {
+            switch (knob(KNOB_ATTN_DBG)) {
+                case 1: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 1>), grid, dim3(256), 0, stream, p); break;
+                case 2: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 2>), grid, dim3(256), 0, stream, p); break;
+                case 4: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 4>), grid, dim3(256), 0, stream, p); break;
+                case 6: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 6>), grid, dim3(256), 0, stream, p); break;
+                case 7: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 7>), grid, dim3(256), 0, stream, p); break;
+                case 8: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 8>), grid, dim3(256), 0, stream, p); break;
+                default: hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, false, false, false, false, false, false, 15>), grid, dim3(256), 0, stream, p); break;
+            }
+        }
+    }
     else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();

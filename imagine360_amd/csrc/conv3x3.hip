@@ -173,8 +173,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     t01 += bt[i][g][0];
                     t23 += bt[i][g][1];
                     }
-                    v01 *= gelu_erf_pk(t01);
-                    v23 *= gelu_erf_pk(t23);
+                    v01 *= gelu_poly_pk(t01);
+                    v23 *= gelu_poly_pk(t23);
                     uint2 o;
                     o.x = pack2<T>(v01.x, v01.y);
                     o.y = pack2<T>(v23.x, v23.y);

@@ -344,6 +344,20 @@ def bench_attn_small(iters):
         print(f"attn_small {name:14s} B={B:4d} H={H:2d} Nq={Nq:5d}: {t * 1e3:8.3f} ms")
 
 
+def bench_attn_ablate(iters):
+    """Where the time of the d = 64 two-query-block flash kernel goes (knob attn_dbg; ablation builds, results are garbage):
+    full | no exp2 | no QK^T MFMAs | no PV MFMAs | no MFMAs | no MFMAs, no exp2 | no K/V staging | skeleton only."""
+    for name, B, H, Nq, Nk in [("pano L0 self", 32, 5, 8192, 8192), ("pers L0 self", 640, 5, 1024, 1024)]:
+        q, k, v = rn(B, Nq, H * 64), rn(B, Nk, H * 64), rn(B, Nk, H * 64)
+        row = []
+        for dbg in (0, 1, 2, 4, 6, 7, 8, 15, 0):
+            K.tuning_set("attn_dbg", dbg)
+            t = timeit(lambda: K.attention(q, k, v, H), iters)
+            row.append(f"dbg={dbg}: {t * 1e3:6.3f}")
+        K.tuning_set("attn_dbg", 0)
+        print(f"attn_ablate {name:14s} (ms) " + " | ".join(row))
+
+
 def bench_xattn(iters):
     """Text + IP cross attention (77 + 64 keys, one context per 16-frame video): generic two-pass kernel (knob attn_x 0) vs
     both key / value sets resident in LDS (1: 16-byte stores, 2: 8-byte stores).  Floor = Q read + O written at HBM speed."""
