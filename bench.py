@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="hipBLASLt default heuristic instead of the shipped solution table")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--warp-streams", type=int, default=1, help="with --dual-stream: the two directions of every WarpAttn on the two streams too")
+    ap.add_argument("--dual-stream", type=int, default=1, help="1 (default): the panorama branch between WarpAttn calls on a side stream (two parallel branches in the hipGraph); 0: one stream")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
                     help="rocprofv3 PMC summary (tools/hbm_traffic.sh) the roofline block quotes HBM traffic from")
     args = ap.parse_args()
@@ -242,6 +244,8 @@ def main():
     if not args.no_tuned_gemms:
         tuned = tuning.enable()
     mv = configs.build_mv_model(args.width_div, device=dev, dtype=dt, xformers=True)
+    mv.dual_stream = bool(args.dual_stream)
+    mv.warp_streams = bool(args.warp_streams)
     # samples: every rank its own sample (seed); frame modes: ONE sample, replicated conditioning, identical RNG streams
     seed = 1 + rank if mode == "samples" else 1
     inp = synthetic.mv_inputs(frames=frames, pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=seed,
@@ -355,11 +359,13 @@ def main():
                 eager_step(i)
         kernels.prof_enable(prof_kinds)
         kernels.STATS, kernels.SHAPES = {}, {}
+        was_dual, mv.dual_stream = mv.dual_stream, False      # one stream: a kernel's events then bracket that kernel alone
         t1 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
         torch.cuda.synchronize()
         eager_elapsed = time.perf_counter() - t1
+        mv.dual_stream = was_dual
         kernels.prof_enable([])
     finite = bool(torch.isfinite(pano_lat.float()).all().item())
 
@@ -376,7 +382,7 @@ def main():
             "scaling": "weak" if mode == "samples" else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tuned_gemm_table": tuned, "tuned_gemm_table_status": (tuning.STATUS if not args.no_tuned_gemms else {"applied": False, "reason": "--no-tuned-gemms"}),
-            "launch": "eager" if graphed is None else "hipGraph replay (one captured step)",
+            "launch": ("eager" if graphed is None else "hipGraph replay (one captured step)") + (", panorama branch on a side stream between the WarpAttn calls" if mv.dual_stream and shard is None else ""),
             "config": {"workload": w["desc"],
                        "parallelism": {"samples": f"sample-parallel x{world}" if world > 1 else "single GPU",
                                        "frames": f"frame-chunk sharding x{world} ({frames // max(world, 1)} frames per GPU)",
@@ -392,7 +398,10 @@ def main():
             shapes, kernels.SHAPES = kernels.SHAPES, None
             out["eager_ms_per_step"] = 1e3 * eager_elapsed / args.steps
             out["profile_source"] = ("HIP events (on the launch stream) around every launch of our kernels during a separate eager pass of "
-                                     "the same K steps, after the timed region; algorithmic flops / bytes counted per launch")
+                                     "the same K steps, after the timed region; algorithmic flops / bytes counted per launch"
+                                     + ("; that pass issues everything on ONE stream so that a kernel's events bracket it alone, whereas in "
+                                        "the timed region the panorama branch's kernels run beside the perspective branch's (side stream): "
+                                        "the per-class durations therefore add up to more than ms_per_step" if was_dual else ""))
             classes = {}
             for kname, (ms, n) in prof.items():
                 fl, by, _, fx = stats.get(kname, [0.0, 0.0, 0, 0.0])

@@ -41,7 +41,17 @@ class DerivedCache:
                 # the entry keeps its sources alive, so their addresses cannot be recycled by another tensor
                 hit = (sig, build(), tuple(params))
             self._store[key] = hit
+            publish_to_all_streams(hit[1])
         return hit[1]
+
+
+def publish_to_all_streams(t):
+    """A cached tensor is built once on whatever stream was current and then read from every stream the model uses
+    (MultiViewBaseModel.dual_stream / cfg_streams): wait for the build before anybody else can be handed the entry.  Cache
+    fills are rare (first use, checkpoint load); a fill during a hipGraph capture stays stream-ordered as before."""
+    ts = t if isinstance(t, (tuple, list)) else (t,)
+    if any(torch.is_tensor(x) and x.is_cuda for x in ts) and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()
 
 
 class InflatedConv3d(nn.Conv2d):

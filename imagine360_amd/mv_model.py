@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import kernels
 from . import pano_geometry as G
-from .layers import DerivedCache, FeedForward, QKVAttention, layer_norm, to_cl
+from .layers import DerivedCache, FeedForward, QKVAttention, layer_norm, publish_to_all_streams, to_cl
 
 
 class SphericalPE(nn.Module):
@@ -83,9 +83,10 @@ class WarpAttn(nn.Module):
                 if packed:
                     b_e2p, b_p2e = kernels.pack_attn_bias(b_e2p), kernels.pack_attn_bias(b_p2e)
                 self._geom[key] = (b_e2p, b_p2e, pers_pe.to(dtype), equi_pe.to(dtype), packed)
+                publish_to_all_streams(self._geom[key][:4])
         return self._geom[key]
 
-    def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None):
+    def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None, side=None):
         """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes.  ``sel``: device int32
         scalar holding the normal (0) / antipodal (1) mask choice; then both variants are handed to the kernel and
         the choice is made on the device, which keeps the whole denoising step replayable from a hipGraph."""
@@ -109,14 +110,31 @@ class WarpAttn(nn.Module):
         pr_n = layer_norm(t.norm1, pr, pre=pers_pe)
         qkv_e, qkv_p = t.attn1.qkv(eq_n), t.attn1.qkv(pr_n)
         h = t.attn1.heads
-        a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel, bias_packed=packed)
-        a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed)
         # residual adds ride in the GEMM epilogues where the token count takes the MFMA kernel (same rounding sequence as
         # Linear -> + residual; hipBLASLt + add otherwise)
-        eq, st = t.attn1.out_proj(a_e, residual=eq, row_stats=True)
-        eq = t.ff(eq, residual=eq, ln=t.norm2, stats=st)              # LayerNorm folded into the GEGLU GEMM where both take the MFMA kernel
-        pr, st = t.attn1.out_proj(a_p, residual=pr, row_stats=True)
-        pr = t.ff(pr, residual=pr, ln=t.norm2, stats=st)
+        def equi_chain(eq):
+            a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel, bias_packed=packed)
+            eq, st = t.attn1.out_proj(a_e, residual=eq, row_stats=True)
+            return t.ff(eq, residual=eq, ln=t.norm2, stats=st)          # LayerNorm folded into the GEGLU GEMM where both take the MFMA kernel
+
+        def pers_chain(pr):
+            a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed)
+            pr, st = t.attn1.out_proj(a_p, residual=pr, row_stats=True)
+            return t.ff(pr, residual=pr, ln=t.norm2, stats=st)
+
+        if side is not None and eq.is_cuda:
+            # once both projections exist the two directions are independent: the panorama's (the smaller grids) on the side
+            # stream.  eq / qkv_e / qkv_p were allocated on this stream and stay referenced by this frame until after the join.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                eq_out = equi_chain(eq)
+            pr = pers_chain(pr)
+            main.wait_stream(side)
+            eq = eq_out
+        else:
+            eq = equi_chain(eq)
+            pr = pers_chain(pr)
         pers_out = pr.reshape(b, frames, m, ph, pw, c).permute(0, 2, 1, 3, 4, 5).reshape(nf, ph, pw, c)
         return pers_out.contiguous(), eq.reshape(ne_img, eh, ew, c)
 
@@ -148,6 +166,33 @@ class MultiViewBaseModel(nn.Module):
         self._coins_dev = None          # int32[8] on the device: the 7 WarpAttn coins of the current step
         self.coins_preloaded = False    # True while a captured graph replays: the driver draws + uploads the coins
         self._ip_noise_half = None      # (half index, 2) when this rank runs one CFG half (BASELINE config 5 layout)
+        self.dual_stream = True         # the panorama branch's segments between WarpAttn calls run on a side stream (GPU, unsharded)
+        self._sharded = False
+        self.warp_streams = True        # with dual_stream: the two directions of every WarpAttn on the two streams as well
+        self._streams = {}
+
+    def _run_pair(self, pers_fn, pano_fn, inputs):
+        """One segment of each branch between two WarpAttn calls (they share nothing but read-only conditioning).  With
+        ``dual_stream`` on a GPU the panorama segment is issued on a side stream forked from / joined back into the current
+        one, so its small grids (16 - 512 workgroups at levels 1 - 3) fill the CUs the perspective kernels' tails leave idle;
+        captured into the step's hipGraph as two parallel branches.  Allocator safety without record_stream: ``inputs`` (the
+        main-stream tensors the side stream reads first) stay referenced until the join, conv_in's output (the last skip the
+        panorama decoder pops) by _trunk's arguments until all segments are done, and everything the side stream allocates is
+        next touched by the main stream only after the join / by the side stream only after the next fork.  Measured on cfg2:
+        327.9 -> 312.9 ms per step (-4.6 %), bit-identical results (test_dual_stream_forward_is_bit_identical_eager_and_graphed)."""
+        x0 = inputs[0]
+        if not (self.dual_stream and not self._sharded and torch.is_tensor(x0) and x0.is_cuda):
+            pers_fn()
+            pano_fn()
+            return
+        main = torch.cuda.current_stream()
+        side = self._stream(0, x0.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pano_fn()
+        pers_fn()
+        main.wait_stream(side)
+        del inputs
 
     def draw_coins(self, device):
         """The reference draws ``random.random() < 0.4`` once per WarpAttn call (src/utils/utils.py:15), 7 per step in
@@ -192,6 +237,7 @@ class MultiViewBaseModel(nn.Module):
         """Frame-chunk sharding (imagine360_amd.dist.FrameShard): the model is fed this rank's frames and every
         motion-module attention exchanges tokens with one all-to-all each way."""
         from .unet3d import VersatileAttention
+        self._sharded = shard is not None       # (collectives of one communicator stay on one stream: no side stream then)
         for mod in self.modules():
             if isinstance(mod, VersatileAttention):
                 mod.frame_shard = shard
@@ -210,6 +256,147 @@ class MultiViewBaseModel(nn.Module):
         if self.noise_on_host:
             return torch.randn(like.shape, dtype=torch.float32).to(device=like.device, dtype=like.dtype)
         return torch.randn_like(like)
+
+    def _stream(self, k, device):
+        st = self._streams.get(k)
+        if st is None or st.device != torch.device(device):
+            st = self._streams[k] = torch.cuda.Stream(device=device)
+        return st
+
+    def _trunk(self, x, px, emb, pemb, ctx, pctx, cams, f, coins):
+        """Everything between conv_in and the output layout for the given rows of the batch: both UNets block by block, the
+        7 WarpAttn, conv_out.  (Measured and dropped: the two rows of the CFG batch as two concurrent trunks on their own streams --
+        half-sized grids per kernel cost more than the filled tails give back: 323 vs 304 ms per cfg2 step.)"""
+        un, pu = self.unet, self.pano_unet
+        pano = self.pano_pad
+        taps = self.taps
+        order = {"enc0": 0, "enc1": 1, "enc2": 2, "mid": 3, "dec0": 4, "dec1": 5, "dec2": 6}
+
+        warp_side = self._stream(0, x.device) if (self.dual_stream and self.warp_streams and not self._sharded and x.is_cuda) else None
+
+        def warp(blk, name, a, e):
+            a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]], side=warp_side)
+            if taps is not None:
+                taps[name] = (a, e)
+            return a, e
+
+        # ---- the two branches between WarpAttn calls are independent: `pair` runs one segment of each, the panorama's on a
+        #      side stream when dual_stream is set (see _run_pair)
+        dbg = getattr(self, "debug_taps", None)
+        skips, pskips = [x], [px]
+        st = {"x": x, "px": px}
+        dbx, dbp = {}, {}              # per-branch debug taps, merged after each segment
+
+        def pair(pers_fn, pano_fn):
+            self._run_pair(pers_fn, pano_fn, (st["x"], st["px"]))
+            if dbg is not None:
+                for k in dbx:
+                    dbg[k] = (dbx[k], dbp[k])
+
+        def down_pers(i):
+            def fn():
+                db, x = un.down_blocks[i], st["x"]
+                for j in range(len(db.resnets)):
+                    x = db.resnets[j].forward_cl(x, emb, f)
+                    dbx[f"res{i}{j}"] = x
+                    if db.has_cross_attention:           # DownBlock3D's motion modules are skipped (:292-303)
+                        x = db.attentions[j].forward_cl(x, ctx, f)
+                        dbx[f"attn{i}{j}"] = x
+                        if db.motion_modules[j] is not None:
+                            x = db.motion_modules[j].forward_cl(x, f)
+                        dbx[f"mm{i}{j}"] = x
+                    skips.append(x)
+                if db.downsamplers is not None:
+                    x = db.downsamplers[0].forward_cl(x)
+                    skips.append(x)
+                st["x"] = x
+            return fn
+
+        def down_pano(i):
+            def fn():
+                pdb, px = pu.down_blocks[i], st["px"]
+                for j in range(len(pdb.resnets)):
+                    px = pdb.resnets[j].forward_cl(px, pemb, f, pano)
+                    dbp[f"res{i}{j}"] = px
+                    if pdb.has_cross_attention:
+                        px = pdb.attentions[j].forward_cl(px, pctx, f)
+                        dbp[f"attn{i}{j}"] = px
+                        if pdb.motion_modules[j] is not None:
+                            px = pdb.motion_modules[j].forward_cl(px, f)
+                        dbp[f"mm{i}{j}"] = px
+                    pskips.append(px)
+                if pdb.downsamplers is not None:
+                    px = pdb.downsamplers[0].forward_cl(px, pano)
+                    pskips.append(px)
+                st["px"] = px
+            return fn
+
+        def up_pers(i, first=None):
+            def fn():
+                x = st["x"]
+                if first is not None:
+                    x = first(x)
+                ub = un.up_blocks[i]
+                for j in range(len(ub.resnets)):
+                    # skip connections: the ResnetBlock reads (x, skip) in place, torch.cat([x, skip]) is never written
+                    x = ub.resnets[j].forward_cl((x, skips.pop()), emb, f)
+                    if ub.has_cross_attention:           # UpBlock3D's motion modules are skipped (:426-443)
+                        x = ub.attentions[j].forward_cl(x, ctx, f)
+                        if ub.motion_modules[j] is not None:
+                            x = ub.motion_modules[j].forward_cl(x, f)
+                st["x"] = x
+            return fn
+
+        def up_pano(i, first=None):
+            def fn():
+                px = st["px"]
+                if first is not None:
+                    px = first(px)
+                pub = pu.up_blocks[i]
+                for j in range(len(pub.resnets)):
+                    px = pub.resnets[j].forward_cl((px, pskips.pop()), pemb, f, pano)
+                    if pub.has_cross_attention:
+                        px = pub.attentions[j].forward_cl(px, pctx, f)
+                        if pub.motion_modules[j] is not None:
+                            px = pub.motion_modules[j].forward_cl(px, f)
+                st["px"] = px
+            return fn
+
+        # ---- down (MVGenModel.py:261-326); the last down block has no downsampler: it runs into the mid block (:336-380)
+        nd = len(un.down_blocks)
+        for i in range(nd):
+            if un.down_blocks[i].downsamplers is not None:
+                pair(down_pers(i), down_pano(i))
+                st["x"], st["px"] = warp(self.cp_blocks_encoder[i], f"enc{i}", st["x"], st["px"])
+            else:
+                assert i == nd - 1, "only the last down block runs into the mid block"
+                dp, dq = down_pers(i), down_pano(i)
+
+                def mid_pers():
+                    dp()
+                    st["x"] = un.mid_block.forward_cl(st["x"], emb, ctx, f)
+
+                def mid_pano():
+                    dq()
+                    st["px"] = pu.mid_block.forward_cl(st["px"], pemb, pctx, f, pano)
+                pair(mid_pers, mid_pano)
+        st["x"], st["px"] = warp(self.cp_blocks_mid, "mid", st["x"], st["px"])
+        # ---- up (:395-458): a block's WarpAttn sits in front of its upsampler, so the upsample opens the next segment
+        up_x = up_px = None
+        for i, (ub, pub) in enumerate(zip(un.up_blocks, pu.up_blocks)):
+            pair(up_pers(i, up_x), up_pano(i, up_px))
+            up_x = up_px = None
+            if ub.upsamplers is not None:
+                st["x"], st["px"] = warp(self.cp_blocks_decoder[i], f"dec{i}", st["x"], st["px"])
+                up_x = (lambda u: (lambda t: u.forward_cl(t)))(ub.upsamplers[0])
+                up_px = (lambda u: (lambda t: u.forward_cl(t, pano)))(pub.upsamplers[0])
+        x, px = st["x"], st["px"]
+        if up_x is not None:           # (not the case for the SD layout: the last up block has no upsampler)
+            x, px = up_x(x), up_px(px)
+        # ---- out (:462-479)
+        x = un.conv_out_cl(x)
+        px = pu.conv_out_cl(px, pano)
+        return x, px
 
     def forward(self, latents, pano_latent, timestep, prompt_embd, pano_prompt_embd, cameras, use_fps_condition,
                 use_ip_plus_cross_attention, fps_tensor_pano, fps_tensor_pers, reference_images_clip_feat_pano,
@@ -246,73 +433,13 @@ class MultiViewBaseModel(nn.Module):
         pctx = torch.cat([pano_prompt_embd.to(dt), ip_pano], dim=1)
         ctx = torch.cat([prompt_embd.to(dt), ip_pers], dim=1)
 
-        pano = self.pano_pad
-        taps = self.taps
         coins = self._coins_dev if self.coins_preloaded else self.draw_coins(x.device)
-        order = {"enc0": 0, "enc1": 1, "enc2": 2, "mid": 3, "dec0": 4, "dec1": 5, "dec2": 6}
-
-        def warp(blk, name, a, e):
-            a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]])
-            if taps is not None:
-                taps[name] = (a, e)
-            return a, e
-
-        # ---- down (MVGenModel.py:261-326)
         dbg = getattr(self, "debug_taps", None)
         if dbg is not None:
             dbg["conv_in"] = (x, px)
             dbg["ctx"] = (ctx, pctx)
             dbg["emb"] = (emb, pemb)
-        skips, pskips = [x], [px]
-        for i, (db, pdb) in enumerate(zip(un.down_blocks, pu.down_blocks)):
-            for j in range(len(db.resnets)):
-                x = db.resnets[j].forward_cl(x, emb, f)
-                px = pdb.resnets[j].forward_cl(px, pemb, f, pano)
-                if dbg is not None:
-                    dbg[f"res{i}{j}"] = (x, px)
-                if db.has_cross_attention:           # DownBlock3D's motion modules are skipped (:292-303)
-                    x = db.attentions[j].forward_cl(x, ctx, f)
-                    px = pdb.attentions[j].forward_cl(px, pctx, f)
-                    if dbg is not None:
-                        dbg[f"attn{i}{j}"] = (x, px)
-                    if db.motion_modules[j] is not None:
-                        x = db.motion_modules[j].forward_cl(x, f)
-                    if pdb.motion_modules[j] is not None:
-                        px = pdb.motion_modules[j].forward_cl(px, f)
-                    if dbg is not None:
-                        dbg[f"mm{i}{j}"] = (x, px)
-                skips.append(x)
-                pskips.append(px)
-            if db.downsamplers is not None:
-                x = db.downsamplers[0].forward_cl(x)
-                px = pdb.downsamplers[0].forward_cl(px, pano)
-                skips.append(x)
-                pskips.append(px)
-                x, px = warp(self.cp_blocks_encoder[i], f"enc{i}", x, px)
-        # ---- mid (:336-380)
-        x = un.mid_block.forward_cl(x, emb, ctx, f)
-        px = pu.mid_block.forward_cl(px, pemb, pctx, f, pano)
-        x, px = warp(self.cp_blocks_mid, "mid", x, px)
-        # ---- up (:395-458)
-        for i, (ub, pub) in enumerate(zip(un.up_blocks, pu.up_blocks)):
-            for j in range(len(ub.resnets)):
-                # skip connections: the ResnetBlock reads (x, skip) in place, torch.cat([x, skip]) is never written
-                x = ub.resnets[j].forward_cl((x, skips.pop()), emb, f)
-                px = pub.resnets[j].forward_cl((px, pskips.pop()), pemb, f, pano)
-                if ub.has_cross_attention:           # UpBlock3D's motion modules are skipped (:426-443)
-                    x = ub.attentions[j].forward_cl(x, ctx, f)
-                    if ub.motion_modules[j] is not None:
-                        x = ub.motion_modules[j].forward_cl(x, f)
-                    px = pub.attentions[j].forward_cl(px, pctx, f)
-                    if pub.motion_modules[j] is not None:
-                        px = pub.motion_modules[j].forward_cl(px, f)
-            if ub.upsamplers is not None:
-                x, px = warp(self.cp_blocks_decoder[i], f"dec{i}", x, px)
-                x = ub.upsamplers[0].forward_cl(x)
-                px = pub.upsamplers[0].forward_cl(px, pano)
-        # ---- out (:462-479)
-        x = un.conv_out_cl(x)
-        px = pu.conv_out_cl(px, pano)
+        x, px = self._trunk(x, px, emb, pemb, ctx, pctx, cams, f, coins)
         co = x.shape[-1]
         sample = x.reshape(b, m, f, h, w, co).permute(0, 1, 5, 2, 3, 4)
         pano_sample = px.reshape(b, f, *px.shape[1:3], co).permute(0, 4, 1, 2, 3)

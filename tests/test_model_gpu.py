@@ -203,6 +203,48 @@ def test_graph_replayed_step_equals_eager_step():
     assert torch.isfinite(g.pano_lat.float()).all()
 
 
+def test_dual_stream_forward_is_bit_identical_eager_and_graphed():
+    """``MultiViewBaseModel.dual_stream``: the panorama branch's segments between WarpAttn calls issued on a side stream
+    (forked from / joined into the current one).  Same kernels on the same data: eager predictions equal the single-stream
+    ones to the last bit, three times in a row (allocator reuse across the two streams), and a hipGraph captured with the
+    two parallel branches replays to the same latents as the single-stream graph."""
+    from imagine360_amd.graph_step import GraphedDenoiseStep
+    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    mv = configs.build_mv_model(5, device=dev, dtype=dt, xformers=True)
+    mv._ip_noise = lambda like: torch.zeros_like(like)
+    cams = S.icosahedron_cameras(90, 128, device=dev)
+    inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=6, sam_frames=16, dtype=dt, device=dev)
+    outs = {}
+    for dual in (False, True, False, True):
+        mv.dual_stream = dual
+        random.seed(9)
+        pp, pn = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **inp)
+        torch.cuda.synchronize()
+        if dual in outs:
+            assert torch.equal(outs[dual][0], pp) and torch.equal(outs[dual][1], pn)
+        outs[dual] = (pp.clone(), pn.clone())
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    sch.set_timesteps(25)
+    ts = sch._timesteps_host
+    lat = {}
+    for dual in (False, True):
+        mv.dual_stream = dual
+        inp2 = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=6, sam_frames=16, dtype=dt, device=dev)
+        pano2, pers2 = inp2["pano_latent"][:1, :4].clone(), inp2["latents"][:1, :, :4].clone()
+        inp2.pop("timestep")
+        g = GraphedDenoiseStep(mv, sch, inp2, cams, pano2, pers2, 7.5)
+        random.seed(5)
+        for i in range(3):
+            g.step(ts[i])
+        torch.cuda.synchronize()
+        lat[dual] = (g.pano_lat.clone(), g.pers_lat.clone())
+        del g
+    mv.dual_stream = False
+    assert torch.equal(lat[False][0], lat[True][0]) and torch.equal(lat[False][1], lat[True][1])
+    assert torch.isfinite(lat[True][0].float()).all()
+
+
 # ------------------------------------------------------------------ full-width blocks, cfg4 / cfg5 sized kernels
 _BLOCK_ORACLE = {}
 
