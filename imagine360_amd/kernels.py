@@ -663,8 +663,9 @@ KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_rin
 
 
 def tuning_set(name, value):
-    """A/B switches of the launchers (tools/bench_kernels.py); none of them changes results.  Defaults are the
-    measured best, see DESIGN.md section 3b'."""
+    """A/B switches of the launchers (tools/bench_kernels.py).  Defaults are the measured best, see DESIGN.md section 3b';
+    conv_halo / conv_cm change the fp32 summation order, attn_x (0 against 1 - 3) and attn_ds the 16-bit rounding points,
+    conv_dbg / attn_dbg break results on purpose, the others do not change results."""
     _check(lib().im360_tuning_set(KNOBS[name], int(value)), "im360_tuning_set")
 
 

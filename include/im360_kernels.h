@@ -251,9 +251,13 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * (builtin / asm LDS-DMA), 4 staggered wave groups, 5 ring kernel for convolutions too; 5 reserved; 6 ablation bits of the
  * ring kernel; 7 halo-patch kernel for the stride-1 3x3 convolutions; 8 taps-innermost K order of the 3x3 convolutions
  * (default 1); 9 packed-rows LayerNorm at 320 channels (default 1); 10 cout groups of the persistent kernel's tile walk:
- * 0 = by weight size, 2 / 4 / 8 forced; 11 text + IP cross attention: 1 (default) key / value sets resident in LDS, 2 the same
- * with 8-byte output stores, 0 the generic two-pass kernel).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
- * change the fp32 summation order, 6 breaks results on purpose, the others do not change results. */
+ * 0 = by weight size, 2 / 4 / 8 forced; 11 text + IP cross attention: 1 key / value sets resident in LDS, 2 the same
+ * with 8-byte output stores, 3 (default) the same on twelve-wave workgroups whose waves fetch their query blocks through private LDS
+ * rings, 0 the generic two-pass kernel; 12 attention row sums as dot2 of the packed weights + v_permlane32_swap max exchange (sums
+ * the ROUNDED weights: results differ in the last bits; default 0); 13 single-buffer / three-waves-per-SIMD attention when there
+ * is one key tile (default 1); 14 ablation builds of the d = 64 two-block attention kernel: results are garbage).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * change the fp32 summation order, 11 (0 against 1 - 3: the scale is folded into K instead of Q) and 12 the 16-bit rounding points, 6 and 14
+ * break results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);
 
 /* HIP-event profiling of kernel classes (bit k of mask enables class k: 0 attn, 1 temporal, 2 conv,
