@@ -70,9 +70,18 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // SIMD -- these launches are thousands of tiny workgroups whose only lever is how many of them a CU holds (43 KB of LDS each
 // allowed three).
 // ABL (knob attn_dbg, tools/bench_kernels.py attn_ablate; results are garbage): 1 no exp2, 2 no QK^T MFMAs, 4 no PV MFMAs, 8 no K / V staging.
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0>
+// HG ("head group", WarpAttn on large grids; knob attn_hg): the NW waves of a workgroup take NW different (batch, head) pairs over the
+// SAME 32 QB query rows instead of NW row blocks of one pair.  The [Nq, Nk] mask is shared by every (batch, head), so the waves'
+// fragment loads could hit the CU's L1 instead of each going to the L2 (tools/warp_bias_probe.py: with the mask fully cached the
+// level-1 launches take 0.82 instead of 0.99 ms).  Every wave stages its own pair's K / V tiles (its own LDS region, 64 lanes per
+// tile).  MEASURED SLOWER, off by default: 1.21 vs 0.96 ms at level 1 (1.08 vs 0.83 with a cached mask) -- four times the K / V
+// staging per query row costs more than the mask traffic it was meant to save, and the mask's share did not shrink (0.13 ms).
+// Bit-identical to the two-query-block kernel (test_attention_head_groups_share_the_mask).
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0, bool HG = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3 : 2, ONE ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
     static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
+    static_assert(!HG || (HAS_BIAS && !DUAL && !BL && !ONE), "head groups share a mask");
+    constexpr int SNT = HG ? 64 : NW * 64;     // threads that stage one K / V tile together
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
     constexpr int NT = NW * 64;
@@ -81,16 +90,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
     constexpr int DC = D / 16;         // k-steps of the QK^T contraction
     constexpr int DV = D / 32;         // 32-wide blocks of the output head dim
     constexpr int CH = KVB * D / 8;    // 16-byte chunks in a K (or V) tile
-    constexpr int CLD = CH / NT;       // chunks per thread
-    constexpr int RSTEP = NT / (D / 8);     // tile rows between a thread's consecutive chunks
-    static_assert(CH % NT == 0 && NT % (D / 8) == 0, "staging pattern");
+    constexpr int CLD = CH / SNT;      // chunks per thread
+    constexpr int RSTEP = SNT / (D / 8);    // tile rows between a thread's consecutive chunks
+    static_assert(CH % SNT == 0 && SNT % (D / 8) == 0, "staging pattern");
     constexpr bool QK_ALL = QB == 1;             // both halves' scores up front (2 * 16 live score registers per block)
     constexpr bool SHARE_K = QB == 1 || D < 64;  // one K fragment read feeds all query blocks
     constexpr int KT = KVB * KP, VT = KVB * VP;  // tile sizes (elements)
 
     // double-buffered K / V tiles: one barrier per KV tile (the next tile is written while this one is consumed)
-    __shared__ __attribute__((aligned(16))) T k_lds2[(ONE ? 1 : 2) * KT];
-    __shared__ __attribute__((aligned(16))) T v_lds2[(ONE ? 1 : 2) * VT];
+    __shared__ __attribute__((aligned(16))) T k_lds_all[(HG ? NW : 1) * (ONE ? 1 : 2) * KT];
+    __shared__ __attribute__((aligned(16))) T v_lds_all[(HG ? NW : 1) * (ONE ? 1 : 2) * VT];
     constexpr bool BF_LDS = BF && QB > 1 && BL;
     constexpr int BROWS = 32 * QB;             // mask rows of one wave
     constexpr int BLD = BROWS * 4 / 64;        // 16-byte loads per lane and 32-key half (4 lanes per 64-byte row segment)
@@ -99,6 +108,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, hi = lane >> 5;
+    T* const k_lds2 = k_lds_all + (HG ? wid * (2 * KT) : 0);       // this wave's (HG) or the workgroup's tile pair
+    T* const v_lds2 = v_lds_all + (HG ? wid * (2 * VT) : 0);
+    const int stid = HG ? lane : tid;
     // XCD-aware block order: the dispatcher deals consecutive block ids round-robin to the 8 XCDs (private L2s).
     // Give every XCD one contiguous range of the (batch*head major, q-tile minor) space, so the ~100 workgroups
     // resident on an XCD at any moment share ONE head's K/V (2 MB at 8192 keys) in that XCD's 4 MB L2 instead of
@@ -112,9 +124,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
     // Nk x d x 4 B of K / V: 4x at d = 32): query tile major, (batch, head) minor, so the workgroups resident on an XCD
     // read the same mask rows out of its L2 and K / V come from the Infinity Cache instead of the other way round.
     const long nbh = (long)p.B * p.H;
-    const int bh = HAS_BIAS ? (int)(lb % nbh) : (int)(lb / p.nqt);
+    const long nbg = nbh / NW;                  // HG: groups of NW pairs (the host checks divisibility)
+    const int bh = HG ? (int)(lb % nbg) * NW + wid : (HAS_BIAS ? (int)(lb % nbh) : (int)(lb / p.nqt));
     const int b = bh / p.H, h = bh % p.H;
-    const int q0 = (int)(HAS_BIAS ? lb / nbh : lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
+    const int q0 = HG ? (int)(lb / nbg) * (32 * QB) : (int)(HAS_BIAS ? lb / nbh : lb % p.nqt) * (32 * NW * QB) + wid * (32 * QB);
 
     const T* qb_ = (const T*)p.q + (long)b * p.q_bs + (long)h * D;
     // the key / value set being processed (DUAL kernels switch to the second set after the first)
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3
 
     // per-thread staging slots: thread tid owns (row, 16-byte chunk) slots tid + i * NT of a tile (rows RSTEP apart),
     // so one source pointer per operand advanced by a tile per load is all the address math
-    const int srow = tid / (D / 8), sc8 = tid % (D / 8);
+    const int srow = stid / (D / 8), sc8 = stid % (D / 8);
     const T* ksrc = kb_ + (long)srow * set_k_rs + sc8 * 8;
     const T* vsrc = vb + (long)srow * set_v_rs + sc8 * 8;
     long k_tile = (long)KVB * set_k_rs, v_tile = (long)KVB * set_v_rs;
@@ -849,6 +862,11 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
             else if (knob(KNOB_ATTN_HL) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);      // A/B: mask rows through the wave's LDS patch (measured 6 % slower: the divergent fragment loads are not the limiter)
+            else if (knob(KNOB_ATTN_HG) && ((long)p.B * p.H) % 4 == 0 && (long)p.B * p.H * ((p.Nq + 63) / 64) / 4 <= 0x7fffffffL) {
+                // head groups: four (batch, head) pairs per workgroup over the same 64 query rows
+                dim3 hgrid((unsigned)((long)p.B * p.H / 4 * ((p.Nq + 63) / 64)), 1, 1);
+                hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, false, false, false, 0, true>), hgrid, dim3(256), 0, stream, p);
+            }
             else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, false, true>), grid, dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();

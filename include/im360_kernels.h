@@ -255,7 +255,8 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * with 8-byte output stores, 3 (default) the same on twelve-wave workgroups whose waves fetch their query blocks through private LDS
  * rings, 0 the generic two-pass kernel; 12 attention row sums as dot2 of the packed weights + v_permlane32_swap max exchange (sums
  * the ROUNDED weights: results differ in the last bits; default 0); 13 single-buffer / three-waves-per-SIMD attention when there
- * is one key tile (default 1); 14 ablation builds of the d = 64 two-block attention kernel: results are garbage).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * is one key tile (default 1); 14 ablation builds of the d = 64 two-block attention kernel: results are garbage; 15 WarpAttn head groups: the four waves of a
+ * workgroup on four (batch, head) pairs over the same query rows, measured slower, default 0).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
  * change the fp32 summation order, 11 (0 against 1 - 3: the scale is folded into K instead of Q) and 12 the 16-bit rounding points, 6 and 14
  * break results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);

@@ -229,6 +229,33 @@ def test_attention_dot_sum_variant(dt):
         K.tuning_set("attn_ds", 0)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 10, 2048, 512), (4, 3, 100, 328), (1, 4, 64, 1280)])
+def test_attention_head_groups_share_the_mask(dt, B, H, Nq, Nk):
+    """Knob attn_hg: the four waves of a workgroup take four (batch, head) pairs over the same 64 query rows (mask fragments
+    then come out of the CU's L1) instead of four row blocks of one pair; every wave stages its own K / V.  Same arithmetic
+    per (pair, row): bit-identical to the two-query-block kernel, ragged rows / keys and the device-side mask switch included."""
+    g = torch.Generator().manual_seed(88)
+    D = 32
+    q, k, v = (q16(torch.randn(B, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
+    bias = q16(torch.where(torch.rand(Nq, Nk, generator=g) < 0.3, 1.0, -1.0) + 0.25 * torch.randn(Nq, Nk, generator=g), dt)
+    dq, dk, dv = (t.to(dt).cuda() for t in (q, k, v))
+    pb, pa = K.pack_attn_bias(bias.to(dt).cuda()), K.pack_attn_bias((-bias).to(dt).cuda())
+    sel = torch.tensor([1], dtype=torch.int32, device="cuda")
+    try:
+        K.tuning_set("attn_qb", 2)
+        outs = []
+        for hg in (0, 1):
+            K.tuning_set("attn_hg", hg)
+            outs.append((K.attention(dq, dk, dv, H, bias=pb, bias_packed=True),
+                         K.attention(dq, dk, dv, H, bias=pb, bias_alt=pa, bias_sel=sel, bias_packed=True)))
+        assert rel(outs[1][0], OU.sdpa(q, k, v, H, bias=bias)) < TOL[dt]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        K.tuning_set("attn_qb", 0)
+        K.tuning_set("attn_hg", 0)
+
+
 def test_attention_softmax_rescale_branch():
     """Force the running max to jump in a late KV tile (spiked key) -- the online-softmax rescale path."""
     dt = torch.bfloat16
