@@ -438,7 +438,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // pre-summed weights (after the upsample every output parity sees only 2 x 2 distinct source pixels): tap (r, c) reads
 // source pixel (y + r + py - 1, x + c + px - 1); 4 / 9 of the MACs of the upsampled form.
 template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN * 16 > 200 ? 1 : 2))) void conv_igemm_kernel(ConvParams p) {
+// (waves per SIMD given as min AND max: with the minimum alone hipcc aimed the 256 x 64 tile at three waves per SIMD -- 168 registers --
+//  and spilled 688 bytes inside the K loop once ConvParams grew in round 3: 1.58 ms instead of 0.25 ms for a cfg1-sized 320 -> 320
+//  convolution; its LDS footprint allows two workgroups per CU anyway)
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM * TN * 16 > 200 ? 1 : 2, TM * TN * 16 > 200 ? 1 : 2))) void conv_igemm_kernel(ConvParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
@@ -1328,7 +1331,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     if (cm) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
-    } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4 && TM == 2)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
+    } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4 && TM == 2) && !(WM == 4 && WN == 1 && knob(KNOB_CONV_SMALL) == 0)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
         hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1432,9 +1435,16 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (linear) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
         return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
     }
-    // a last 128-wide cout tile that is at most half full wastes MFMA work: use 256 x 64 tiles instead
+    // Cout % 128 in (0, 64] (the UNet's 320 on grids too small for the 256 x 320 tile, i.e. every cfg1-sized launch): rounds 1 - 2
+    // used 256 x 64 tiles so that no cout tile is half empty.  Since round 3 the 64-channel instantiation of that tile spills 688
+    // bytes inside its K loop (ConvParams grew; hipcc aims it at 168 registers whatever amdgpu_waves_per_eu says): 1.98 ms for a
+    // 320 -> 320 convolution of 320 16 x 16 images -- cfg1's conv class went 21.8 -> 61.1 ms unnoticed, the headline config does not
+    // use this tile.  Measured (bench_kernels.py conv_small): 256 x 64 with 32-channel K steps 0.281 ms, plain 128 x 128 tiles
+    // 0.228 ms (taps innermost, 17 % of the MFMA work wasted on the half-empty tile all the same).  Knob conv_small: 2 = 128 x 128
+    // (default), 0 = 256 x 64 / 32 channels, 1 = 256 x 64 / 64 channels.
     const int rem = p.Cout % 128;
-    if (rem != 0 && rem <= 64 && p.Cout > 64) return launch_conv_t<T, 4, 1, 2, 2>(p, stream);
+    const int small = knob(KNOB_CONV_SMALL);
+    if (rem != 0 && rem <= 64 && p.Cout > 64 && small != 2) return launch_conv_t<T, 4, 1, 2, 2>(p, stream);
     return launch_conv_t<T, 2, 2, 2, 2>(p, stream);
 }
 

@@ -115,6 +115,25 @@ def bench_conv(iters):
               f"({fl / t / 2.5e15 * 100:4.1f}% of MFMA peak)")
 
 
+def bench_conv_small(iters):
+    """cfg1-sized convolutions with Cout = 320 (too few tiles for the 256 x 320 tile): 256 x 64 tiles with 32- (knob conv_small 0)
+    or 64-channel K steps (1: spills since round 3), or 128 x 128 tiles (2, default)."""
+    shapes = [("cfg1 pers L0 320->320", 320, 16, 16, 320, 320), ("cfg1 pers up L0 960->320", 320, 16, 16, 960, 320),
+              ("cfg1 pano L0 320->320 (W+4)", 16, 32, 68, 320, 320), ("cfg1 pers up L0 640->320", 320, 16, 16, 640, 320)]
+    for name, N, H, W, Ci, Co in shapes:
+        x = rn(N, H, W, Ci)
+        w = K.pack_conv_weight(rn(Co, Ci, 3, 3) * (9 * Ci) ** -0.5)
+        b = rn(Co)
+        fl = 2.0 * N * H * W * Ci * Co * 9
+        row = []
+        for pol in (0, 1, 2, 0):
+            K.tuning_set("conv_small", pol)
+            t = timeit(lambda: K.conv2d(x, w, Co, bias=b), iters)
+            row.append(f"conv_small={pol}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.0f} TF/s")
+        K.tuning_set("conv_small", 2)
+        print(f"conv_small {name:28s}: " + " | ".join(row))
+
+
 def bench_up2(iters):
     """Upsample3D convolutions: nearest-x2 folded into the 9-tap kernel's addressing vs four 2x2 convolutions of the
     low-resolution input (sub-pixel form, 4/9 of the MACs).  TF/s are quoted on the 9-tap flop count for both."""
