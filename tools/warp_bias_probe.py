@@ -3,6 +3,7 @@
 through a zero row stride (every fragment load hits the L1 / L2); and the head-group form (knob attn_hg)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from imagine360_amd import kernels as K
 from bench_kernels import timeit, rn, DT, DEV
 torch.set_grad_enabled(False)
