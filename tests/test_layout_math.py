@@ -150,3 +150,100 @@ def test_mfma32_c_fragment_rows():
     for c, hi in itertools.product(range(2), range(2)):
         assert [rows(r, hi) for r in range(8 * c, 8 * c + 8)] == \
             [16 * c + 4 * hi + j for j in range(4)] + [16 * c + 8 + 4 * hi + j for j in range(4)]
+
+
+# ---------------------------------------------------------------- attn_fwd.hip: resident-K/V cross attention (xattn_resident_kernel)
+@pytest.mark.parametrize("Bkv,H,kv_group,Nq,nwv", [(40, 5, 16, 1024, 12), (2, 5, 16, 8192, 12), (3, 4, 2, 320, 4), (1, 5, 1, 1024, 4),
+                                                  (2, 20, 16, 32, 4), (1, 1, 1, 32, 4), (3, 5, 2, 1056, 4), (4, 5, 16, 1024, 12)])
+def test_xattn_block_walk_covers_every_query_block_once(Bkv, H, kv_group, Nq, nwv):
+    """The kernel deals contiguous ranges of the (pair, frame, 32-row block) sequence to workgroups, segments a range at pair
+    boundaries (K / V re-staged), strides a segment over the workgroup's waves and advances (frame, block) without divisions;
+    the LDS-DMA variant requests two blocks ahead and re-requests the wave's last block past the end.  Every block is processed
+    exactly once, by the slot its request went to, and nothing ever indexes past a video's frames."""
+    nqb = (Nq + 31) // 32
+    bpp = kv_group * nqb
+    total = Bkv * H * bpp
+    per = min(max(total // 1024, 8), 48)
+    G = 256 * -(-total // (144 * 256)) if nwv == 12 else -(-total // per)
+    seen = set()
+    for w in range(G):
+        r0, r1 = total * w // G, total * (w + 1) // G
+        j = r0
+        while j < r1:
+            pair = j // bpp
+            seg_end, base = min(r1, (pair + 1) * bpp), pair * bpp
+            for wid in range(nwv):
+                jj = j + wid
+                g, qb = divmod(jj - base, nqb)
+                # request stream of the ring variant: (block index requested, slot)
+                req, jr, gr, qr = [], jj, g, qb
+                def request(slot):
+                    nonlocal jr, gr, qr
+                    req.append(((gr, qr), slot))
+                    if jr + nwv < seg_end:
+                        jr += nwv
+                        qr += nwv
+                        while qr >= nqb:
+                            qr -= nqb
+                            gr += 1
+                if jj < seg_end:
+                    request(0)
+                    request(1)
+                it = 0
+                while jj < seg_end:
+                    assert 0 <= g < kv_group and 0 <= qb < nqb and (g, qb) == divmod(jj - base, nqb)
+                    # the newest request into slot it & 1 before this iteration's refill is this block's
+                    assert [r for r, s in req if s == (it & 1)][-1] == (g, qb)
+                    assert (pair, g, qb) not in seen
+                    seen.add((pair, g, qb))
+                    request(it & 1)
+                    if jj + nwv < seg_end:
+                        qb += nwv
+                        while qb >= nqb:
+                            qb -= nqb
+                            g += 1
+                    jj += nwv
+                    it += 1
+            j = seg_end
+    assert len(seen) == total
+
+
+def test_xattn_query_ring_swizzle_is_conflict_free():
+    """global_load_lds piece i, lane l lands at ring byte (64 i + l) * 16 = row (8 i + l / 8), chunk position l % 8, and was
+    given data chunk (l % 8) ^ ((row >> 1) & 7) of that query row as its source; the fragment read of lane (col, hi), k-step dc
+    goes to position (2 dc + hi) ^ ((col >> 1) & 7) of row col.  They meet, every row arrives as one whole 128-byte line, and
+    each 16-lane group of the ds_read_b128 touches all 64 banks once."""
+    lds = {}
+    for i in range(4):
+        for lane in range(64):
+            row, pos = 8 * i + lane // 8, lane % 8
+            assert (64 * i + lane) * 16 == row * 128 + pos * 16
+            lds[(row, pos)] = pos ^ ((row >> 1) & 7)                     # data chunk stored there
+        for row in range(8 * i, 8 * i + 8):
+            assert sorted(lds[(row, p)] for p in range(8)) == list(range(8))
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for dc in range(4):
+        for lane in range(64):
+            col, hi = lane & 31, lane >> 5
+            assert lds[(col, (2 * dc + hi) ^ ((col >> 1) & 7))] == 2 * dc + hi
+        for grp in groups:
+            acc = [((l & 31) * 128 + (((2 * dc + (l >> 5)) ^ (((l & 31) >> 1) & 7)) << 4), 16) for l in grp]
+            assert worst_conflict(acc, 64) == 1
+
+
+def test_xattn_wide_store_exchange():
+    """v_permlane32_swap(first, second) exchanges lanes 32-63 of `first` with lanes 0-31 of `second`.  With first = this lane's
+    8 bytes of column group g, second = its 8 bytes of group g + 1 (lane (col, hi) holds channels 8 g' + 4 hi .. + 3), every
+    lane ends up with the 16 contiguous bytes of channels 8 (g + hi) .. + 7 of its query row, low half first."""
+    for g in (0, 2):
+        first = {l: ("g", g, l >> 5, l & 31) for l in range(64)}           # (group, hi of the owner, query col)
+        second = {l: ("g", g + 1, l >> 5, l & 31) for l in range(64)}
+        f2, s2 = dict(first), dict(second)
+        for l in range(32):
+            f2[l + 32], s2[l] = second[l], first[l + 32]
+        for l in range(64):
+            col, hi = l & 31, l >> 5
+            lo, hi_half = f2[l], s2[l]
+            grp = g + hi
+            assert lo == ("g", grp, 0, col) and hi_half == ("g", grp, 1, col)    # channels 8 grp + 0..3 then + 4..7, same row
