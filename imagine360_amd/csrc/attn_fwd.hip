@@ -77,8 +77,11 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // tile).  MEASURED SLOWER, off by default: 1.21 vs 0.96 ms at level 1 (1.08 vs 0.83 with a cached mask) -- four times the K / V
 // staging per query row costs more than the mask traffic it was meant to save, and the mask's share did not shrink (0.13 ms).
 // Bit-identical to the two-query-block kernel (test_attention_head_groups_share_the_mask).
-template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0, bool HG = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(ONE ? 3 : 2, ONE ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
+// W3 (knob attn_w3, one query block per wave, d = 64): three waves per SIMD (<= 168 registers) instead of two, i.e. three workgroups
+// per CU -- for the short sequences of the perspective branch, where a workgroup's prologue is a large share of its life.
+template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0, bool HG = false, bool W3 = false>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((ONE || W3) ? 3 : 2, (ONE || W3) ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
+    static_assert(!W3 || (QB == 1 && !DUAL && !HAS_BIAS), "three-waves-per-SIMD variant");
     static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
     static_assert(!HG || (HAS_BIAS && !DUAL && !BL && !ONE), "head groups share a mask");
     constexpr int SNT = HG ? 64 : NW * 64;     // threads that stage one K / V tile together
@@ -849,6 +852,12 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int qb_env = knob(KNOB_ATTN_QB);       // tuning override
     int qb = 1;
     if (nw == 4 && (qb_env == 2 || (qb_env == 0 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 1024))) qb = 2;
+    // Round 3: at d = 64 without a bias, ONE block per wave at THREE waves per SIMD (148 registers, no scratch; three 43 KB
+    // workgroups per CU) beats the two-block form on every self-attention shape of the step: panorama level 0 2.99 -> 2.95 ms,
+    // perspective level 0 1.10 -> 1.07, level 1 0.414 -> 0.397 / 0.218 -> 0.209, panorama level 2 0.072 -> 0.064
+    // (bench_kernels.py attn_w3; one block at two waves per SIMD: 3.14 / 1.19).  Knob attn_w3 0 restores the rule above.
+    const bool w3 = !HAS_BIAS && D == 64 && nw == 4 && qb_env != 2 && knob(KNOB_ATTN_W3) != 0 && knob(KNOB_ATTN_DBG) == 0 && !(qb_env == 1 && knob(KNOB_ATTN_DS));
+    if (w3) qb = 1;
     p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);
     const long nblk = (long)p.B * p.H * p.nqt;
     if (nblk > 0x7fffffffL) {
@@ -882,6 +891,13 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
             if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, false, false, false, false, false, true>), grid, dim3(64), 0, stream, p);
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, false, false, false, false, false, true>), grid, dim3(128), 0, stream, p);
             else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, false, false, false, false, false, true>), grid, dim3(256), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if constexpr (!HAS_BIAS && D == 64) {
+        if (w3 && !(p.Nk <= KVB && knob(KNOB_ATTN_ONE))) {
+            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, false, false, false, false, false, false, 0, false, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }

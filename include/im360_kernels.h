@@ -257,7 +257,8 @@ int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect);
  * the ROUNDED weights: results differ in the last bits; default 0); 13 single-buffer / three-waves-per-SIMD attention when there
  * is one key tile (default 1); 14 ablation builds of the d = 64 two-block attention kernel: results are garbage; 15 WarpAttn head groups: the four waves of a
  * workgroup on four (batch, head) pairs over the same query rows, measured slower, default 0; 16 tiles of
- * convolutions with Cout % 128 in (0, 64] on small grids: 2 (default) 128 x 128, 0 / 1 256 x 64 with 32- / 64-channel K steps).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
+ * convolutions with Cout % 128 in (0, 64] on small grids: 2 (default) 128 x 128, 0 / 1 256 x 64 with 32- / 64-channel K steps; 17 d = 64 attention without a bias on four-wave grids: 1 (default)
+ * one query block per wave at three waves per SIMD, 0 the round-2 rule (two blocks per wave on large grids)).  Defaults are the measured best; the IM360_* environment variables seed them at load time.  Knobs 7 and 8
  * change the fp32 summation order, 11 (0 against 1 - 3: the scale is folded into K instead of Q) and 12 the 16-bit rounding points, 6 and 14
  * break results on purpose, the others do not change results. */
 int im360_tuning_set(int knob, int value);

@@ -377,6 +377,25 @@ def bench_attn_ablate(iters):
         print(f"attn_ablate {name:14s} (ms) " + " | ".join(row))
 
 
+def bench_attn_w3(iters):
+    """d = 64 self-attention: the default rule (two query blocks per wave on large grids) vs one block per wave at two and at
+    three waves per SIMD (knobs attn_qb 1, attn_w3 1)."""
+    shapes = [("pano L0 self", 32, 5, 8192, 8192), ("pers L0 self", 640, 5, 1024, 1024), ("pano L1 self", 32, 10, 2048, 2048),
+              ("pers L1 self", 640, 10, 256, 256), ("pano L2 self", 32, 20, 512, 512)]
+    for name, B, H, Nq, Nk in shapes:
+        q, k, v = rn(B, Nq, H * 64), rn(B, Nk, H * 64), rn(B, Nk, H * 64)
+        fl = 4.0 * B * H * Nq * Nk * 64
+        row = []
+        for qb, w3 in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 1)):
+            K.tuning_set("attn_qb", qb)
+            K.tuning_set("attn_w3", w3)
+            t = timeit(lambda: K.attention(q, k, v, H), iters)
+            row.append(f"qb={qb} w3={w3}: {t * 1e3:7.3f} ms {fl / t / 2.5e15 * 100:4.1f}%")
+        K.tuning_set("attn_qb", 0)
+        K.tuning_set("attn_w3", 0)
+        print(f"attn_w3 {name:14s} " + " | ".join(row))
+
+
 def bench_xattn(iters):
     """Text + IP cross attention (77 + 64 keys, one context per 16-frame video): generic two-pass kernel (knob attn_x 0) vs
     both key / value sets resident in LDS (1: 16-byte stores, 2: 8-byte stores).  Floor = Q read + O written at HBM speed."""
