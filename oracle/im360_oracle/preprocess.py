@@ -14,7 +14,9 @@ What is pinned and what is not:
     into the smallest / largest of its taps (2..3, 2..3) -- as remembered from initInterTab2D, and the only reading under
     which an integer-coordinate sample, whose centre tap saturates at 32767, still returns the source pixel --, round-half-
     even coordinate quantisation, modulo border, (sum + 2^14) >> 15 saturated to uint8).  None of this can be checked
-    against OpenCV here; the residue rule moves single results by at most 1 LSB.
+    against OpenCV here; the residue rule moves single results by at most 1 LSB.  What IS checked (round 3,
+    tests/test_oracle_golden.py::test_remap_restatement_tracks_an_independent_bicubic): agreement to 1 LSB with torch's
+    float bicubic grid_sample (same A = -0.75 kernel) at 1/32-pixel coordinates incl. wrap-around taps.
 """
 import math
 

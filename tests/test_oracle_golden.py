@@ -136,6 +136,43 @@ def test_sr_close_loop_pad_against_reference():
         OG.padding_pano(g["lat"][0, 0, 0], 16, latent=True)
 
 
+def test_remap_restatement_tracks_an_independent_bicubic():
+    """cv2 is not in this image, so the oracle's restatement of cv2.remap(INTER_CUBIC, BORDER_WRAP) (and with it the HIP
+    kernel, which the GPU tier holds to it bit for bit) cannot be pinned on OpenCV itself.  It CAN be held against an
+    independent implementation of the same published algorithm that IS here: torch's bicubic grid_sample (Keys kernel,
+    A = -0.75, float arithmetic) on a circularly padded image.  At coordinates that are exact multiples of 1/32 pixel -- where
+    OpenCV's coordinate quantisation is exact, leaving only its 2^-15 weight table and the final rounding -- the two agree to
+    1 LSB everywhere and exactly on > 99 % of the samples, wrap-around taps in both axes included: kernel, tap alignment,
+    border mode and rounding are the published ones.  At arbitrary coordinates on a smooth image the 1/32-pixel quantisation
+    costs at most 2 LSB more."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from im360_oracle import preprocess as P
+    rng = np.random.default_rng(0)
+    H, W, h, w, pad = 40, 64, 50, 70, 4
+
+    def torch_bicubic(img, mx, my):
+        t = F.pad(torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None], (pad, pad, pad, pad), mode="circular")
+        gx = (torch.from_numpy(mx.astype(np.float64)) + pad) / (W + 2 * pad - 1) * 2 - 1
+        gy = (torch.from_numpy(my.astype(np.float64)) + pad) / (H + 2 * pad - 1) * 2 - 1
+        out = F.grid_sample(t, torch.stack([gx, gy], -1)[None], mode="bicubic", padding_mode="border", align_corners=True)
+        return out[0].permute(1, 2, 0).numpy()
+
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)                          # white noise: the hardest image
+    mx = (rng.integers(-48, (W + 1) * 32, (h, w)) / 32.0).astype(np.float32)       # from -1.5 to W + 1: wraps on both sides
+    my = (rng.integers(-48, (H + 1) * 32, (h, w)) / 32.0).astype(np.float32)
+    d = np.abs(P.remap_cubic_wrap_u8(img, mx, my).astype(np.int64) - np.clip(np.rint(torch_bicubic(img, mx, my)), 0, 255).astype(np.int64))
+    assert d.max() <= 1 and (d == 0).mean() > 0.99, (d.max(), (d == 0).mean())
+    yy, xx = np.mgrid[0:H, 0:W]
+    smooth = np.stack([127.5 + 120 * np.sin(2 * np.pi * (xx / W + c * yy / H)) * np.cos(2 * np.pi * yy / H) for c in (1, 2, 3)], -1)
+    smooth = np.clip(np.rint(smooth), 0, 255).astype(np.uint8)                     # periodic in both axes, like a panorama in W
+    fx = rng.uniform(-1.5, W + 1, (h, w)).astype(np.float32)
+    fy = rng.uniform(-1.5, H + 1, (h, w)).astype(np.float32)
+    d = np.abs(P.remap_cubic_wrap_u8(smooth, fx, fy).astype(np.int64) - np.clip(np.rint(torch_bicubic(smooth, fx, fy)), 0, 255).astype(np.int64))
+    assert d.max() <= 3, d.max()
+
+
 def test_preprocessing_geometry_against_reference():
     """the oracle's E2P / P2E sampling maps and masks == the maps the REAL Equirec2Perspec / Perspec2Equirec
     modules hand to cv2.remap, and its get_maxrec_cord == the real one (tests/golden/preproc.npz), bit-exact.  (cv2.remap's
