@@ -81,7 +81,7 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // per CU -- for the short sequences of the perspective branch, where a workgroup's prologue is a large share of its life.
 template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0, bool HG = false, bool W3 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((ONE || W3) ? 3 : 2, (ONE || W3) ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
-    static_assert(!W3 || (QB == 1 && !DUAL && !HAS_BIAS), "three-waves-per-SIMD variant");
+    static_assert(!W3 || (QB == 1 && !DUAL && !BL), "three-waves-per-SIMD variant");
     static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
     static_assert(!HG || (HAS_BIAS && !DUAL && !BL && !ONE), "head groups share a mask");
     constexpr int SNT = HG ? 64 : NW * 64;     // threads that stage one K / V tile together
@@ -869,6 +869,7 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
         if (p.bias_packed) {
             if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, true, false, true>), grid, dim3(64), 0, stream, p);
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
+            else if (qb == 1 && knob(KNOB_ATTN_W3) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true, false, false, false, 0, false, true>), grid, dim3(256), 0, stream, p);      // A/B (attn_qb 1 + attn_w3 2): WarpAttn with one block per wave at three waves per SIMD -- 1.13 ms against 0.98 for the two-block form (which shares every K fragment and mask prefetch between its blocks) and 1.25 at two waves: off
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
             else if (knob(KNOB_ATTN_HL) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);      // A/B: mask rows through the wave's LDS patch (measured 6 % slower: the divergent fragment loads are not the limiter)
             else if (knob(KNOB_ATTN_HG) && ((long)p.B * p.H) % 4 == 0 && (long)p.B * p.H * ((p.Nq + 63) / 64) / 4 <= 0x7fffffffL) {

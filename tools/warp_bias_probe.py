@@ -18,4 +18,11 @@ for name, B, H, Nq, Nk in [("warp L1 e2p", 32, 10, 2048, 5120), ("warp L1 p2e", 
             t = timeit(lambda: K.attention(q, k, v, H, bias=b, bias_packed=True), 10)
             row.append(f"hg={hg} {nm}: {t * 1e3:6.3f} ms")
     K.tuning_set("attn_hg", 0)
+    for qb, w3 in ((0, 1), (1, 1), (1, 2), (0, 1), (1, 2)):          # the rule (two blocks per wave) vs one block at two / three waves per SIMD
+        K.tuning_set("attn_qb", qb)
+        K.tuning_set("attn_w3", w3)
+        t = timeit(lambda: K.attention(q, k, v, H, bias=bb, bias_packed=True), 10)
+        row.append(f"qb={qb} w3={w3}: {t * 1e3:6.3f} ms")
+    K.tuning_set("attn_qb", 0)
+    K.tuning_set("attn_w3", 1)
     print(f"{name}: " + " | ".join(row))
