@@ -72,10 +72,25 @@ def sdpa(q, k, v, heads, bias=None, scale=None):
     qh = q.reshape(B, Nq, heads, d).transpose(1, 2)
     kh = k.reshape(B, -1, heads, d).transpose(1, 2)
     vh = v.reshape(B, -1, heads, d).transpose(1, 2)
-    s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5 if scale is None else scale)
-    if bias is not None:
-        s = s + bias
-    o = torch.matmul(s.softmax(-1), vh)
+    sc = d ** -0.5 if scale is None else scale
+
+    def one(qh, kh, vh, bias):
+        s = torch.matmul(qh, kh.transpose(-1, -2)) * sc
+        if bias is not None:
+            s = s + bias
+        return torch.matmul(s.softmax(-1), vh)
+    # (batch, head) chunks that keep the score matrix under ~2 GB (cfg2-sized fixtures: 8192^2 and 8192 x 20480 score
+    # matrices); the entries are independent, so the numbers do not change
+    Nk = kh.shape[2]
+    per = max(1, int(2e9 // (4 * Nq * Nk)))
+    if per >= B * heads or (bias is not None and bias.dim() > 2):
+        o = one(qh, kh, vh, bias)
+    else:
+        qf, kf, vf = qh.reshape(B * heads, Nq, d), kh.reshape(B * heads, Nk, d), vh.reshape(B * heads, Nk, d)
+        o = torch.empty(B * heads, Nq, d, dtype=qh.dtype)
+        for i in range(0, B * heads, per):
+            o[i:i + per] = one(qf[i:i + per], kf[i:i + per], vf[i:i + per], bias)
+        o = o.reshape(B, heads, Nq, d)
     return _st(o.transpose(1, 2).reshape(B, Nq, C))
 
 

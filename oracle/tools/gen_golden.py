@@ -276,6 +276,57 @@ def gen_mvfull():
          storage_only_bf16=torch.tensor(cal[torch.bfloat16]), storage_only_fp16=torch.tensor(cal[torch.float16]))
 
 
+def gen_mvfull2():
+    """The same at the BENCHMARKED size (BASELINE cfg2: 16 frames, 512x1024 equirect = 64x128 latent, 20 views of 32x32, CFG
+    batch 2, full width): one forward of the REAL reference in fp32 on bf16-rounded filler weights / inputs.  The xformers
+    stand-in and the oracle chunk their attention over (batch, head) so the 8192^2 / 8192 x 20480 score matrices fit.
+    Stores both predictions as fp16 (3.7 MB) plus the storage-only calibration; ~15 min per forward on 8 cores, ~35 GB."""
+    print("[mvfull2] full-width reference forward at cfg2 shapes (about an hour in total)")
+    bf = torch.bfloat16
+    cfg = sd21_unet_cfg(1)
+    cfg.xformers = True
+    mv = RB.ref_mv(cfg)
+    for prm in mv.parameters():
+        prm.data = prm.data.to(bf).float()
+    for mod in mv.modules():
+        if mod.__class__.__name__ == "IPCrossAttention":
+            mod._use_memory_efficient_attention_xformers = True
+    inp = S.mv_inputs(frames=16, pano_hw=(64, 128), pers_hw=(32, 32), seed=1, sam_frames=16)
+    inp = {k: (v.to(bf).float() if torch.is_floating_point(v) and k not in S.FP32_INPUTS else v) for k, v in inp.items()}
+    cams = S.icosahedron_cameras(90, 256)
+    torch.manual_seed(7)
+    random.seed(7)
+    t0 = time.time()
+    rp, rn = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **inp)
+    print(f"  reference forward {time.time() - t0:.1f}s", flush=True)
+    out = dict(pano=rn.half(), pers=rp.half())
+    save("mv_forward_full_cfg2.npz", **out)             # the reference's numbers are safe on disk before the oracle passes
+    sd = dict(mv.state_dict())
+    del mv
+    args = (sd, cfg, inp["latents"], inp["pano_latent"], inp["timestep"], inp["prompt_embd"], inp["pano_prompt_embd"], cams,
+            inp["fps_tensor_pano"], inp["fps_tensor_pers"], inp["reference_images_clip_feat_pano"],
+            inp["reference_images_clip_feat_pers"], inp["relative_position_tensor"], inp["pitchs_tensor"])
+    masks = {}
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(7)
+        random.seed(7)
+        t0 = time.time()
+        with OU.storage(dt):
+            cp, cn = OMV.mv_forward(*args, mask_cache=masks)
+        cal = (rel(cn, rn), rel(cp, rp))
+        print(f"  storage-only {dt}: pano {cal[0]:.3e} pers {cal[1]:.3e}  ({time.time() - t0:.0f}s)", flush=True)
+        out["storage_only_" + ("bf16" if dt == torch.bfloat16 else "fp16")] = torch.tensor(cal)
+        save("mv_forward_full_cfg2.npz", **out)
+        del cp, cn
+    torch.manual_seed(7)
+    random.seed(7)
+    t0 = time.time()
+    op_, on = OMV.mv_forward(*args, mask_cache=masks)
+    print(f"  oracle forward {time.time() - t0:.0f}s", flush=True)
+    out["oracle_vs_reference"] = torch.tensor([check("mvfull2 pano", on, rn), check("mvfull2 pers", op_, rp)])
+    save("mv_forward_full_cfg2.npz", **out)
+
+
 def gen_pipeline(steps=2, frames=16, width_div=5, name="pipeline_w5.npz", keep=None, motion_heads=8):
     print("[pipeline]", name)
     R = ref_shims.ref_modules()

@@ -90,10 +90,23 @@ def _create_meshgrid(h, w, normalized_coordinates=True, device=None, dtype=None)
 def _mea(q, k, v, attn_bias=None, p=0.0, scale=None, op=None):
     if scale is None:
         scale = q.shape[-1] ** -0.5
-    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
-    if attn_bias is not None:
-        s = s + attn_bias.float()
-    return torch.matmul(s.softmax(-1), v.float()).to(q.dtype)
+
+    def one(q, k, v, b):
+        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
+        if b is not None:
+            s = s + b.float()
+        return torch.matmul(s.softmax(-1), v.float()).to(q.dtype)
+    # (batch * head) chunks that keep the score matrix under ~2 GB: the cfg2-sized fixtures (8192^2 self-attention,
+    # 8192 x 20480 cross-view attention) would otherwise need 43 / 215 GB.  Batch entries are independent: same numbers.
+    n = q.shape[0]
+    per = max(1, int(2e9 // (4 * q.shape[-2] * k.shape[-2])))
+    if q.dim() != 3 or per >= n:
+        return one(q, k, v, attn_bias)
+    out = torch.empty(q.shape[:-1] + (v.shape[-1],), dtype=q.dtype)
+    for i in range(0, n, per):
+        b = None if attn_bias is None else (attn_bias[i:i + per] if attn_bias.dim() == 3 and attn_bias.shape[0] == n else attn_bias)
+        out[i:i + per] = one(q[i:i + per], k[i:i + per], v[i:i + per], b)
+    return out
 
 
 class _SamStub:
