@@ -22,32 +22,11 @@
 //     gfx950's transposing LDS read (ds_read_b64_tr_b16), rows padded to 192 B (d = 64) so the 4 key rows one
 //     read touches fall into distinct bank windows.  All fragment reads are base-register + immediate offset.
 #include "common.h"
+#include "attn_params.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace im360 {
-
-struct AttnParams {
-    const void* q; const void* k; const void* v; const void* bias; void* out;
-    const void* bias_alt; const int* bias_sel;     // *bias_sel != 0 -> use bias_alt (decided on the device: graph-replay safe)
-    int B, H, Nq, Nk;
-    int nqt;             // query tiles per (batch, head)
-    int kv_group;        // K/V batch index = query batch index / kv_group (context shared by the frames of a video)
-    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, bias_rs;   // element strides
-    float scale_log2;    // logit scale * log2(e)
-    float out_scale;     // multiplies the normalised result
-    int accumulate;      // out += result instead of out = result
-    int bias_packed;     // bias / bias_alt are fp16 matrices pre-multiplied by log2(e) (im360_attn_pack_bias)
-    // optional SECOND key/value set of the same queries (DUAL kernels): out = out_scale * attn(q, k, v) + out_scale2 *
-    // attn(q, k2, v2), two independent softmaxes -- the text + IP-adapter cross attention in ONE launch
-    const void* k2; const void* v2;
-    int Nk2;
-    long k2_bs, k2_rs, v2_bs, v2_rs;
-    float out_scale2;
-    // resident-K/V cross attention (xattn_resident_kernel): query blocks (32 rows) per image, per (K/V batch, head) pair, in total
-    int x_nqb, x_bpp;
-    long x_total;
-};
 
 constexpr int KVB = 64;            // keys per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -80,7 +59,7 @@ constexpr float RESCALE_THR = 5.0f;   // log2 units: P stays <= 32 between resca
 // W3 (knob attn_w3, one query block per wave, d = 64): three waves per SIMD (<= 168 registers) instead of two, i.e. three workgroups
 // per CU -- for the short sequences of the perspective branch, where a workgroup's prologue is a large share of its life.
 template <typename T, int D, int NW, int QB, bool HAS_BIAS, bool DUAL = false, bool BF = false, bool BL = false, bool DS = false, bool ONE = false, int ABL = 0, bool HG = false, bool W3 = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((ONE || W3) ? 3 : 2, (ONE || W3) ? 3 : 2))) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? (ONE ? 2 : 1) : ((ONE || W3) ? 3 : 2), NW == 1 ? (ONE ? 2 : 1) : ((ONE || W3) ? 3 : 2)))) void attn_fwd_kernel(AttnParams p) {      // (one-wave workgroups stage 16 chunks per lane: 190 - 300 registers)
     static_assert(!W3 || (QB == 1 && !DUAL && !BL), "three-waves-per-SIMD variant");
     static_assert(!ONE || (QB == 1 && !DUAL), "single-tile variant");
     static_assert(!HG || (HAS_BIAS && !DUAL && !BL && !ONE), "head groups share a mask");
@@ -841,6 +820,14 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(RAG2 &
     if constexpr (QDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Rejected / ablation variants (knobs attn_dbg, attn_hl, attn_hg, attn_ds, attn_w3 = 2) are compiled only into `make ablate`
+// builds (-DIM360_ABLATE; im360_build_flags() bit 0): in the shipped library those knobs read as 0.
+#ifdef IM360_ABLATE
+#define IM360_ABL_KNOB(k) knob(k)
+#else
+#define IM360_ABL_KNOB(k) 0
+#endif
+
 template <typename T, int D, bool HAS_BIAS>
 static int launch_attn_b(AttnParams p, hipStream_t stream) {
     const int nw = p.Nq <= 32 ? 1 : (p.Nq <= 64 ? 2 : 4);
@@ -856,7 +843,7 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     // workgroups per CU) beats the two-block form on every self-attention shape of the step: panorama level 0 2.99 -> 2.95 ms,
     // perspective level 0 1.10 -> 1.07, level 1 0.414 -> 0.397 / 0.218 -> 0.209, panorama level 2 0.072 -> 0.064
     // (bench_kernels.py attn_w3; one block at two waves per SIMD: 3.14 / 1.19).  Knob attn_w3 0 restores the rule above.
-    const bool w3 = !HAS_BIAS && D == 64 && nw == 4 && qb_env != 2 && knob(KNOB_ATTN_W3) != 0 && knob(KNOB_ATTN_DBG) == 0 && !(qb_env == 1 && knob(KNOB_ATTN_DS));
+    const bool w3 = !HAS_BIAS && D == 64 && nw == 4 && qb_env != 2 && knob(KNOB_ATTN_W3) != 0 && IM360_ABL_KNOB(KNOB_ATTN_DBG) == 0 && !(qb_env == 1 && IM360_ABL_KNOB(KNOB_ATTN_DS));
     if (w3) qb = 1;
     p.nqt = (p.Nq + 32 * nw * qb - 1) / (32 * nw * qb);
     const long nblk = (long)p.B * p.H * p.nqt;
@@ -869,8 +856,11 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
         if (p.bias_packed) {
             if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, true, false, true>), grid, dim3(64), 0, stream, p);
             else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, true, false, true>), grid, dim3(128), 0, stream, p);
+#ifdef IM360_ABLATE
             else if (qb == 1 && knob(KNOB_ATTN_W3) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true, false, false, false, 0, false, true>), grid, dim3(256), 0, stream, p);      // A/B (attn_qb 1 + attn_w3 2): WarpAttn with one block per wave at three waves per SIMD -- 1.13 ms against 0.98 for the two-block form (which shares every K fragment and mask prefetch between its blocks) and 1.25 at two waves: off
+#endif
             else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, true, false, true>), grid, dim3(256), 0, stream, p);
+#ifdef IM360_ABLATE
             else if (knob(KNOB_ATTN_HL) == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, true>), grid, dim3(256), 0, stream, p);      // A/B: mask rows through the wave's LDS patch (measured 6 % slower: the divergent fragment loads are not the limiter)
             else if (knob(KNOB_ATTN_HG) && ((long)p.B * p.H) % 4 == 0 && (long)p.B * p.H * ((p.Nq + 63) / 64) / 4 <= 0x7fffffffL) {
                 // head groups: four (batch, head) pairs per workgroup over the same 64 query rows
@@ -878,6 +868,7 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
                 hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, false, false, false, 0, true>), hgrid, dim3(256), 0, stream, p);
             }
             else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true, false, true>), grid, dim3(256), 0, stream, p);
+#endif
             else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, true, false, true>), grid, dim3(256), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
@@ -886,6 +877,13 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     if (p.bias_packed) {
         im360_set_error("attn_fwd: packed bias matrices are supported for head dim 32 only");
         return IM360_ERR_UNSUPPORTED;
+    }
+    if constexpr (!HAS_BIAS && D == 64) {
+        // software-pipelined kernel (attn_pipe.hip; knob attn_pipe): the self-attention shapes with whole 64-key tiles
+        if (nw == 4 && IM360_ABL_KNOB(KNOB_ATTN_DBG) == 0) {
+            const int rc = launch_attn_pipe(p, std::is_same<T, __bf16>::value ? 0 : 1, stream);
+            if (rc != 1) return rc;
+        }
     }
     if constexpr (!HAS_BIAS && D == 64) {
         if (p.Nk <= KVB && qb == 1 && knob(KNOB_ATTN_ONE)) {
@@ -905,8 +903,11 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
     }
     if (nw == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 1, 1, HAS_BIAS>), grid, dim3(64), 0, stream, p);
     else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 2, 1, HAS_BIAS>), grid, dim3(128), 0, stream, p);
+#ifdef IM360_ABLATE
     else if (qb == 1 && knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
+#endif
     else if (qb == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 1, HAS_BIAS>), grid, dim3(256), 0, stream, p);
+#ifdef IM360_ABLATE
     else if (!HAS_BIAS && D == 64 && knob(KNOB_ATTN_DBG)) {
         if constexpr (!HAS_BIAS && D == 64) {
             switch (knob(KNOB_ATTN_DBG)) {
@@ -921,6 +922,7 @@ static int launch_attn_b(AttnParams p, hipStream_t stream) {
         }
     }
     else if (knob(KNOB_ATTN_DS)) hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS, false, false, false, true>), grid, dim3(256), 0, stream, p);
+#endif
     else hipLaunchKernelGGL((attn_fwd_kernel<T, D, 4, 2, HAS_BIAS>), grid, dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;

@@ -16,6 +16,7 @@ _I64, _F32, _INT, _PTR = ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_
 
 _SIGNATURES = {
     "im360_abi_version": (_INT, []),
+    "im360_build_flags": (_INT, []),
     "im360_last_error": (ctypes.c_char_p, []),
     "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR]),
     "im360_attn_fwd2": (_INT, [_PTR] * 6 + [_I64] * 19 + [_F32, _F32, _F32, _INT, _PTR]),
@@ -659,7 +660,15 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
 
 # ------------------------------------------------------------------------------------------ tuning knobs
 KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9,
-         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17}
+         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18}
+
+
+ATTN_PIPE_DEFAULT = -1         # the library's default for the attn_pipe knob (abi.cpp)
+
+
+def ablate_build():
+    """True when the library was built with `make ablate` (rejected A/B variants and ablation kernels compiled in)."""
+    return bool(lib().im360_build_flags() & 1)
 
 
 def tuning_set(name, value):

@@ -17,6 +17,8 @@ extern "C" {
 #endif
 
 int im360_abi_version(void);
+/* bit 0: ablation build (`make ablate`): the rejected A/B kernel variants behind the attn_dbg / attn_hl / attn_hg / attn_ds knobs exist */
+int im360_build_flags(void);
 const char* im360_last_error(void);
 
 /* softmax(Q K^T * scale + bias) V, head dim D in {32, 64}; head h of batch b lives at

@@ -187,7 +187,7 @@ def test_attention_packed_bias_through_the_matrix_pipe(dt, B, H, Nq, Nk):
             out = K.attention(dq, dk, dv, H, bias=pb, bias_packed=True)
             assert rel(out, ref) < TOL[dt] and blockrel(out, ref, 32) < 2 * TOL[dt], qb
             assert rel(out, K.attention(dq, dk, dv, H, bias=db).float().cpu()) < TOL[dt]
-            if qb == 2:      # knob attn_hl = 2: the wave's mask rows fetched coalesced and passed through its LDS patch instead of
+            if qb == 2 and K.ablate_build():      # knob attn_hl = 2: the wave's mask rows fetched coalesced and passed through its LDS patch instead of
                 try:         # per-lane fragments straight from global memory -- the same arithmetic, so the same bits
                     K.tuning_set("attn_hl", 2)
                     assert torch.equal(K.attention(dq, dk, dv, H, bias=pb, bias_packed=True), out)
@@ -208,6 +208,8 @@ def test_attention_dot_sum_variant(dt):
     """Knob attn_ds: row sums as dot2's over the packed (rounded) weights and the half-wave max exchange through
     v_permlane32_swap, on the four-wave kernels: d = 64 (one / two query blocks per wave, ragged keys, a spiked key that moves
     the running max late) and d = 32 with the packed bias -- against the oracle and close to the plain variant."""
+    if not K.ablate_build():
+        pytest.skip("rejected A/B variant: only in `make ablate` builds of the library")
     g = torch.Generator().manual_seed(87)
     try:
         for H, D, Nq, Nk, has_bias, qb in ((2, 64, 512, 200, False, 1), (2, 64, 512, 1096, False, 2), (4, 32, 600, 328, True, 2), (4, 32, 256, 640, True, 1)):
@@ -235,6 +237,8 @@ def test_attention_head_groups_share_the_mask(dt, B, H, Nq, Nk):
     """Knob attn_hg: the four waves of a workgroup take four (batch, head) pairs over the same 64 query rows (mask fragments
     then come out of the CU's L1) instead of four row blocks of one pair; every wave stages its own K / V.  Same arithmetic
     per (pair, row): bit-identical to the two-query-block kernel, ragged rows / keys and the device-side mask switch included."""
+    if not K.ablate_build():
+        pytest.skip("rejected A/B variant: only in `make ablate` builds of the library")
     g = torch.Generator().manual_seed(88)
     D = 32
     q, k, v = (q16(torch.randn(B, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
@@ -254,6 +258,31 @@ def test_attention_head_groups_share_the_mask(dt, B, H, Nq, Nk):
     finally:
         K.tuning_set("attn_qb", 0)
         K.tuning_set("attn_hg", 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("knob", [1, 2, 3, 4, 9, 10, 17, 25, 33, 65, 66, 81])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 256, 192), (1, 2, 200, 128), (1, 1, 2048, 2048), (3, 1, 128, 640), (1, 5, 1024, 1024)])
+def test_attention_pipelined_kernel(dt, knob, B, H, Nq, Nk):
+    """attn_pipe.hip (software-pipelined d = 64 self-attention, every schedule, four- and eight-wave workgroups) against the
+    fp32 oracle and against attn_fwd_kernel: odd and even tile counts, a ragged last query block, a spiked key that forces
+    the deferred rescale in a late tile."""
+    D = 64
+    q, k, v = (q16(rnd(B, n, H * D, seed=s), dt) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    k[0, Nk - 70, :D] = q[0, 5, :D] * 5.0            # head 0: the running max jumps in the second to last tile
+    k[0, 9, :D] = q[0, 40, :D] * 7.0                  # ... and in the first one
+    ref = OU.sdpa(q, k, v, H)
+    qd, kd, vd = q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda()
+    try:
+        K.tuning_set("attn_pipe", 0)
+        base = K.attention(qd, kd, vd, H)             # attn_fwd_kernel
+        K.tuning_set("attn_pipe", knob)
+        out = K.attention(qd, kd, vd, H)
+    finally:
+        K.tuning_set("attn_pipe", K.ATTN_PIPE_DEFAULT)
+    assert rel(out, ref) < TOL[dt] and blockrel(out, ref, 32) < 2 * TOL[dt]
+    assert (out.float().cpu() - ref).abs().max() < 0.05
+    assert rel(out, base) < 2e-3                      # same arithmetic up to the order of the fp32 row sums
 
 
 def test_attention_softmax_rescale_branch():

@@ -100,6 +100,36 @@ def bench_attn_variants(iters):
         print(f"attn  {name:14s} two launches {t2 * 1e3:7.3f} ms | one launch (attn_fwd2) {t1 * 1e3:7.3f} ms")
 
 
+def bench_attn_pipe(iters):
+    """d = 64 self-attention: attn_fwd_kernel (knob attn_pipe 0) against the software-pipelined kernel, every schedule, four-
+    and eight-wave workgroups; alternated on the same tensors."""
+    shapes = [("pano L0 self", 32, 5, 8192, 8192), ("pers L0 self", 640, 5, 1024, 1024), ("pano L1 self", 32, 10, 2048, 2048),
+              ("pers L1 self", 640, 10, 256, 256), ("pano L2 self", 32, 20, 512, 512), ("pano L3 self", 32, 20, 128, 128)]
+    if os.environ.get("IM360_ABL"):
+        shapes = shapes[:2]
+    knobs = [0, 1, 9, 10, 25, 65, 66, 81] + ([] if not os.environ.get('IM360_ABL') else [1 + 256 * a for a in (1, 2, 3, 4, 5, 11)])
+    for name, B, H, Nq, Nk in shapes:
+        D = 64
+        q, k, v = rn(B, Nq, H * D), rn(B, Nk, H * D), rn(B, Nk, H * D)
+        fl = 4.0 * B * H * Nq * Nk * D
+        best = {}
+        for rnd_ in range(3):
+            for kb in knobs:
+                K.tuning_set("attn_pipe", kb)
+                t = timeit(lambda: K.attention(q, k, v, H), iters)
+                best[kb] = min(best.get(kb, 1e9), t)
+        K.tuning_set("attn_pipe", K.ATTN_PIPE_DEFAULT)
+        print(f"attn_pipe {name:14s} " + " | ".join(f"{kb}: {best[kb] * 1e3:6.3f} ms {fl / best[kb] / 2.5e15 * 100:4.1f}%" for kb in knobs), flush=True)
+
+
+def bench_attn_self(iters):
+    """The two big d = 64 self-attention shapes with whatever the IM360_ATTN_PIPE environment variable selected (for PMC passes)."""
+    for name, B, H, Nq, Nk in [("pano L0 self", 32, 5, 8192, 8192), ("pers L0 self", 640, 5, 1024, 1024)]:
+        q, k, v = rn(B, Nq, H * 64), rn(B, Nk, H * 64), rn(B, Nk, H * 64)
+        t = timeit(lambda: K.attention(q, k, v, H), iters)
+        print(f"attn_self {name}: {t * 1e3:.3f} ms  {4.0 * B * H * Nq * Nk * 64 / t / 2.5e15 * 100:.1f}% of MFMA peak")
+
+
 def bench_conv(iters):
     shapes = [("pers L0 320->320", 640, 32, 32, 320, 320, False), ("pano L0 320->320 (W+4)", 32, 64, 132, 320, 320, False),
               ("pers L1 640->640", 640, 16, 16, 640, 640, False), ("pers L2 1280->1280", 640, 8, 8, 1280, 1280, False),
