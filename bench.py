@@ -368,6 +368,41 @@ def main():
         mv.dual_stream = was_dual
         kernels.prof_enable([])
     finite = bool(torch.isfinite(pano_lat.float()).all().item())
+    # parity of the BENCHMARKED launch mode at the benchmarked size (outside the timed region, one step): from identical
+    # latents, RNG states and timestep, the captured two-stream hipGraph against the same step issued eagerly on one stream
+    parity_check = None
+    if rank == 0 and shard is None and graphed is not None:
+        import random
+        p0, q0 = graphed.pano_lat.clone(), graphed.pers_lat.clone()
+        py_state, dev_state = random.getstate(), torch.cuda.get_rng_state(dev)
+        i_chk = args.warmup + args.steps
+        graphed.step(ts_host[i_chk % nsteps_total])
+        torch.cuda.synchronize()
+        g_pano, g_pers = graphed.pano_lat.clone(), graphed.pers_lat.clone()
+        res = {}
+        for name, dual in (("eager_one_stream", False), ("eager_two_streams", True)):
+            random.setstate(py_state)
+            torch.cuda.set_rng_state(dev_state, dev)
+            pano_lat, pers_lat = p0.clone(), q0.clone()
+            was_dual, mv.dual_stream, mv.dual_stream_eager = mv.dual_stream, dual, dual
+            eager_step(i_chk)
+            torch.cuda.synchronize()
+            mv.dual_stream, mv.dual_stream_eager = was_dual, False
+            res[name] = (pano_lat.clone(), pers_lat.clone())
+        relf = lambda a, b: float(((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item())
+        e_pano, e_pers = res["eager_one_stream"]
+        parity_check = {
+            "what": "one denoising step at the benchmarked size from identical latents / RNG states: the replayed hipGraph (the timed "
+                    "launch mode) against the same step issued eagerly on ONE stream; relative L2 of the updated latents",
+            "graph_dual_vs_eager_rel": max(relf(g_pano, e_pano), relf(g_pers, e_pers)),
+            "graph_dual_vs_eager_pano_rel": relf(g_pano, e_pano), "graph_dual_vs_eager_pers_rel": relf(g_pers, e_pers),
+            "graph_dual_vs_eager_bit_identical": bool(torch.equal(g_pano, e_pano) and torch.equal(g_pers, e_pers)),
+            "eager_two_streams_vs_one_bit_identical": bool(torch.equal(res["eager_two_streams"][0], e_pano) and torch.equal(res["eager_two_streams"][1], e_pers)),
+            "eager_two_streams_vs_one_rel": max(relf(res["eager_two_streams"][0], e_pano), relf(res["eager_two_streams"][1], e_pers)),
+            "step_changed_the_latents_rel": relf(g_pano, p0),
+        }
+        if parity_check["graph_dual_vs_eager_rel"] > 1e-3:      # (bit-identical in practice; hipBLASLt may pick another solution under capture)
+            raise SystemExit(f"bench.py: the benchmarked launch mode disagrees with the eager single-stream step: {parity_check}")
 
     if rank == 0:
         boc = tuple(mv.unet.config.block_out_channels)
@@ -382,13 +417,14 @@ def main():
             "scaling": "weak" if mode == "samples" else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tuned_gemm_table": tuned, "tuned_gemm_table_status": (tuning.STATUS if not args.no_tuned_gemms else {"applied": False, "reason": "--no-tuned-gemms"}),
-            "launch": ("eager" if graphed is None else "hipGraph replay (one captured step)") + (", panorama branch on a side stream between the WarpAttn calls" if mv.dual_stream and shard is None else ""),
+            "launch": ("eager, one stream" if graphed is None else "hipGraph replay (one captured step)") + (", panorama branch on a side stream between the WarpAttn calls" if mv.dual_stream and shard is None and graphed is not None else ""),
             "config": {"workload": w["desc"],
                        "parallelism": {"samples": f"sample-parallel x{world}" if world > 1 else "single GPU",
                                        "frames": f"frame-chunk sharding x{world} ({frames // max(world, 1)} frames per GPU)",
                                        "cfgxframes": f"CFG halves x frame chunks (2 x {world // 2})"}[mode],
                        "width_div": args.width_div, "ddim_steps_schedule": nsteps_total, "guidance": guidance,
                        "tflop_per_step": total / 1e12, "outputs_finite": finite},
+            "parity_check": parity_check,
             "whole_step_tflops": total / 1e12 * steps_per_s / world,          # per GPU
             "whole_step_frac_of_mfma_peak": total / 1e12 * steps_per_s / world / MFMA_PEAK_TFLOPS,
         }

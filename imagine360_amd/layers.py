@@ -37,6 +37,10 @@ class DerivedCache:
         sig = tuple((p.data_ptr(), p._version, p.dtype, p.device, tuple(p.shape), p.stride()) for p in params if p is not None)
         hit = self._store.get(key)
         if hit is None or hit[0] != sig:
+            if params and params[0] is not None and params[0].is_cuda and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                # a fill inside a capture would be replayed with every step and, in a two-stream capture, be built on one
+                # stream and read unsynchronised on the other: graph_step.GraphedDenoiseStep warms every cache up first
+                raise RuntimeError(f"derived-tensor cache miss ({key!r}) during a hipGraph capture: run the step eagerly once before capturing it")
             with torch.no_grad():
                 # the entry keeps its sources alive, so their addresses cannot be recycled by another tensor
                 hit = (sig, build(), tuple(params))

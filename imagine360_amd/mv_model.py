@@ -168,6 +168,7 @@ class MultiViewBaseModel(nn.Module):
         self._ip_noise_half = None      # (half index, 2) when this rank runs one CFG half (BASELINE config 5 layout)
         self.dual_stream = True         # the panorama branch's segments between WarpAttn calls run on a side stream (GPU, unsharded)
         self._sharded = False
+        self.dual_stream_eager = False  # (tests / A-B only) use the side stream for eagerly issued steps too; see _two_streams
         self.warp_streams = True        # with dual_stream: the two directions of every WarpAttn on the two streams as well
         self._streams = {}
 
@@ -181,7 +182,7 @@ class MultiViewBaseModel(nn.Module):
         next touched by the main stream only after the join / by the side stream only after the next fork.  Measured on cfg2:
         327.9 -> 312.9 ms per step (-4.6 %), bit-identical results (test_dual_stream_forward_is_bit_identical_eager_and_graphed)."""
         x0 = inputs[0]
-        if not (self.dual_stream and not self._sharded and torch.is_tensor(x0) and x0.is_cuda):
+        if not (self._two_streams() and torch.is_tensor(x0) and x0.is_cuda):
             pers_fn()
             pano_fn()
             return
@@ -193,6 +194,16 @@ class MultiViewBaseModel(nn.Module):
         pers_fn()
         main.wait_stream(side)
         del inputs
+
+    def _two_streams(self):
+        """The side stream is used inside a hipGraph capture (where stream dependencies become graph edges and memory comes from
+        the graph's private pool) -- the default, timed path; verified bit-identical to the one-stream eager step at full size by
+        bench.py's parity_check and tests/test_model_gpu.py.  Eagerly issued steps stay on one stream unless ``dual_stream_eager``
+        is set: round 4 found the eager two-stream step at cfg2 size intermittently not bit-identical (one bench run in two),
+        i.e. a lifetime hazard across the two allocator pools that capture does not have; eager issue is host-bound anyway."""
+        if not self.dual_stream or self._sharded:
+            return False
+        return self.dual_stream_eager or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
     def draw_coins(self, device):
         """The reference draws ``random.random() < 0.4`` once per WarpAttn call (src/utils/utils.py:15), 7 per step in
@@ -272,7 +283,7 @@ class MultiViewBaseModel(nn.Module):
         taps = self.taps
         order = {"enc0": 0, "enc1": 1, "enc2": 2, "mid": 3, "dec0": 4, "dec1": 5, "dec2": 6}
 
-        warp_side = self._stream(0, x.device) if (self.dual_stream and self.warp_streams and not self._sharded and x.is_cuda) else None
+        warp_side = self._stream(0, x.device) if (self._two_streams() and self.warp_streams and x.is_cuda) else None
 
         def warp(blk, name, a, e):
             a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]], side=warp_side)

@@ -215,6 +215,7 @@ def test_dual_stream_forward_is_bit_identical_eager_and_graphed():
     cams = S.icosahedron_cameras(90, 128, device=dev)
     inp = S.mv_inputs(frames=8, pano_hw=(32, 64), pers_hw=(16, 16), seed=6, sam_frames=16, dtype=dt, device=dev)
     outs = {}
+    mv.dual_stream_eager = True          # (eager two-stream issue is opt-in: see MultiViewBaseModel._two_streams)
     for dual in (False, True, False, True):
         mv.dual_stream = dual
         random.seed(9)
@@ -380,6 +381,81 @@ def test_full_width_cfg1_step_and_vae_frame_vs_reference_fixture(dt):
         assert errs[name + "_pers"] <= 1.25 * cal_pers + 2e-4, errs
         assert errs[name + "_worst_view"] <= 2 * cal_pers + 2e-4, errs
     assert errs["vae_decode_full_width"] < (2e-2 if dt == torch.bfloat16 else 3e-3), errs
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_full_width_cfg2_step_vs_reference_fixture_in_every_launch_mode(dt):
+    """The BENCHMARKED configuration itself (BASELINE cfg2: full width, 16 frames, 64x128 panorama latent + 20 views of 32x32,
+    CFG batch 2 -- src/models/MVGenModel.py:59-481 at the shapes of configs/prompt-dual.yaml:59-72):
+    (1) one dual-branch forward against what the REAL reference computed in fp32 for the same bf16-rounded weights, inputs and
+        seeds (tests/golden/mv_forward_full_cfg2.npz, oracle/tools/gen_golden.py mvfull2: 17 minutes of host time there), within
+        1.25x of what 16-bit storage alone costs on this network (the fixture's calibration);
+    (2) the same forward issued eagerly with the panorama branch on the side stream (opt-in mode; recorded, not asserted);
+    (3) one whole denoising step (forward + CFG + DDIM) replayed from the captured two-stream hipGraph -- the launch mode
+        bench.py times -- against the step issued eagerly on one stream from the same latents and RNG states."""
+    from imagine360_amd.graph_step import GraphedDenoiseStep
+    g = gold("mv_forward_full_cfg2.npz")
+    dev = torch.device("cuda", 0)
+    mv = configs.build_mv_model(1, device=dev, dtype=torch.bfloat16, xformers=True).to(dt)      # the fixture's weights: filler rounded to bf16
+    mv.noise_on_host = True
+    inp = S.mv_inputs(frames=16, pano_hw=(64, 128), pers_hw=(32, 32), seed=1, sam_frames=16)
+    inp = {k: (v.to(torch.bfloat16) if torch.is_floating_point(v) and k not in S.FP32_INPUTS else v) for k, v in inp.items()}
+    cams = S.icosahedron_cameras(90, 256)
+    dinp = S.cast_mv_inputs(inp, dev, dt)
+    dcams = S.icosahedron_cameras(90, 256, device=dev)
+    views = [int(v) for v in g["pers_view_index"]] if "pers_view_index" in g else list(range(20))
+    o_pers, o_pano = g["pers"].float(), g["pano"].float()
+    cal_pano, cal_pers = (float(v) for v in g["storage_only_bf16" if dt == torch.bfloat16 else "storage_only_fp16"])
+    errs = {"storage_only_pano": cal_pano, "storage_only_pers": cal_pers}
+    outs = {}
+    mv.dual_stream_eager = True          # informational: the eager two-stream forward (opt-in; the default issues eager steps on one stream)
+    for dual in (False, True):
+        mv.dual_stream = dual
+        torch.manual_seed(7)
+        random.seed(7)
+        pers, pano = mv(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True, **dinp)
+        torch.cuda.synchronize()
+        outs[dual] = (pers.clone(), pano.clone())
+    pers, pano = outs[False][0].float().cpu()[:, views], outs[False][1].float().cpu()
+    errs["pano"], errs["pers"] = rel(pano, o_pano), rel(pers, o_pers)
+    d = (pers - o_pers).flatten(3).norm(dim=(2, 3)) / o_pers.flatten(3).norm(dim=(2, 3))
+    errs["worst_view"] = float(d.max())
+    dp = (pano - o_pano).permute(0, 2, 1, 3, 4).flatten(2).norm(dim=2) / o_pano.permute(0, 2, 1, 3, 4).flatten(2).norm(dim=2)
+    errs["worst_pano_frame"] = float(dp.max())
+    errs["eager_two_streams_bit_identical"] = bool(torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]))
+    mv.dual_stream_eager = False
+    # (3) the timed launch mode: captured two-stream graph vs eager one-stream step, IP-adapter noise from the device generator
+    mv.noise_on_host = False
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    sch.set_timesteps(25)
+    ts = sch._timesteps_host
+    ginp = {k: v.clone() for k, v in dinp.items() if k != "timestep"}
+    p0, q0 = ginp["pano_latent"][:1, :4].clone(), ginp["latents"][:1, :, :4].clone()
+    mv.dual_stream = True
+    gs = GraphedDenoiseStep(mv, sch, ginp, dcams, p0, q0, 7.5, warmup=1)
+    py_state, dev_state = random.getstate(), torch.cuda.get_rng_state(dev)
+    gs.step(ts[3])
+    torch.cuda.synchronize()
+    g_pano, g_pers = gs.pano_lat.clone(), gs.pers_lat.clone()
+    del gs
+    mv.dual_stream = False
+    random.setstate(py_state)
+    torch.cuda.set_rng_state(dev_state, dev)
+    einp = {k: v.clone() for k, v in dinp.items()}
+    einp["pano_latent"][:, :4] = p0
+    einp["latents"][:, :, :4] = q0
+    einp["timestep"] = torch.tensor([ts[3]], dtype=torch.int64, device=dev)
+    pp, pn = mv(cameras=dcams, use_fps_condition=True, use_ip_plus_cross_attention=True, **einp)
+    e_pano = sch.fused_cfg_step(pn[0:1], pn[1:2], 7.5, ts[3], p0)
+    e_pers = sch.fused_cfg_step(pp[0:1], pp[1:2], 7.5, ts[3], q0)
+    errs["graph_two_streams_vs_eager_pano"], errs["graph_two_streams_vs_eager_pers"] = rel(g_pano, e_pano), rel(g_pers, e_pers)
+    errs["graph_bit_identical"] = bool(torch.equal(g_pano, e_pano) and torch.equal(g_pers, e_pers))
+    errs["step_moved_the_latent"] = rel(g_pano, p0)
+    _record(f"full_width_cfg2_step_{str(dt).split('.')[-1]}", **errs)
+    assert errs["pano"] <= 1.25 * cal_pano + 2e-4 and errs["pers"] <= 1.25 * cal_pers + 2e-4, errs
+    assert errs["worst_view"] <= 2 * cal_pers + 2e-4 and errs["worst_pano_frame"] <= 2 * cal_pano + 2e-4, errs
+    assert errs["graph_two_streams_vs_eager_pano"] < 1e-5 and errs["graph_two_streams_vs_eager_pers"] < 1e-5, errs
+    assert errs["step_moved_the_latent"] > 1e-2, errs
 
 
 def test_cfg5_sized_kernels_fp16():
