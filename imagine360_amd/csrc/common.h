@@ -175,7 +175,8 @@ __device__ __forceinline__ void lds_dma16_asm(const void* gsrc, uint32_t lds_dst
 // two waves of a SIMD), and v_rcp / v_exp cost ~10 cycles each against 2 for a plain or packed VALU instruction -- the
 // A&S form above is ~31 cycles per value, this one ~13.  Phi(u) - 1/2 = u Q(u^2) on u = clamp(x, -4.2, 4.2), Q of degree 8
 // (least squares on Chebyshev nodes; max |error| of Phi 8.9e-6 in fp32 Horner form, checked over [-8, 8] in steps of 4e-5:
-// 50x below fp16 output rounding; beyond the clamp Phi stays at Phi(4.2) = 1 - 1.3e-5).  v_med3 + 10 packed fp32 ops per pair.
+// 50x below fp16 output rounding; beyond the clamp Phi stays at Phi(4.2) = 1 - 1.3e-5 / Phi(-4.2) = 1.3e-5).  v_med3 + v_max + 10
+// packed fp32 ops per pair.
 __device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 x) {
     const f32x2 u = {__builtin_amdgcn_fmed3f(x.x, -4.2f, 4.2f), __builtin_amdgcn_fmed3f(x.y, -4.2f, 4.2f)};
     const f32x2 t = u * u;
@@ -187,7 +188,11 @@ __device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 x) {
     q = q * t + 9.818162748e-03f;
     q = q * t + (-6.634533366e-02f);
     q = q * t + 3.989019316e-01f;
-    return x * (u * q + 0.5f);
+    // beyond the clamp the factor in front of Phi follows the clamp on the negative side only: x Phi(4.2) = x (1 - 1.3e-5) for
+    // large x, but max(x, -4.2) Phi(-4.2) = -5.6e-5 instead of x * 1.3e-5 for very negative gates (exact GELU tends to -0 there;
+    // round 3's form grew linearly: -4e-4 at x = -30)
+    const f32x2 xm = {fmaxf(x.x, -4.2f), fmaxf(x.y, -4.2f)};
+    return xm * (u * q + 0.5f);
 }
 
 // compile-time unrolled loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>), for bodies that need the index as

@@ -1320,6 +1320,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 3 && TN == 5));
     const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
     p.dbg = knob(KNOB_CONV_DBG);
+#ifdef IM360_ABLATE
     if constexpr (((WM == 4 && WN == 2) || (WM == 2 && WN == 2 && TM == 3)) && TN == 5 && EPI == 0) {
         if (p.dbg && p.Cin % 64 == 0) {         // ablation build of the 256 x 320 conv tile (results are garbage)
             if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1328,6 +1329,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
             return IM360_OK;
         }
     }
+#endif
     if (cm) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1373,16 +1375,20 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     if constexpr (EPI >= 3) {                   // LayerNorm-folded / statistics-writing epilogues: the default pipeline only
         hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     } else {
+#ifdef IM360_ABLATE
     if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false, 0>), dim3(grid), dim3(512), 0, stream, p);
     else if (variant == 3) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 0>), dim3(grid), dim3(512), 0, stream, p);
     else if (variant == 4) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 1>), dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+    else
+#endif
+    hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }
 
 // the halo kernel's tile geometry, or false when the problem does not fit it (the streaming kernels take it then)
+#ifdef IM360_ABLATE
 static bool halo_geometry(ConvParams& p) {
     if (p.ntaps != 9 || p.stride != 1 || p.up || p.wrap || p.y_off != 0 || p.x_off < 0) return false;
     if (p.Cout % 320 != 0 || p.Cin % 32 != 0 || p.Cin < 64 || p.Hin != p.Hout) return false;
@@ -1413,6 +1419,8 @@ static int launch_halo(ConvParams p, hipStream_t stream) {
     return IM360_OK;
 }
 
+#endif
+
 template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
     const int big_env = knob(KNOB_CONV_BIG);           // tuning overrides
@@ -1420,6 +1428,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
     // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
     if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
         const bool linear = p.ntaps == 1 && p.Hin == 1 && p.Win == 1 && !p.temb;       // EPI 2 has no temb add
+#ifdef IM360_ABLATE
         if (knob(KNOB_CONV_HALO)) {
             ConvParams ph = p;
             if (halo_geometry(ph)) return launch_halo<T>(ph, stream);
@@ -1428,6 +1437,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
         // A/B: the same 256 x 320 tile on FOUR waves (128 x 160 each, 320 accumulators in the unified 512-register file, one
         // wave per SIMD): 144 instead of 224 KB of fragment reads per K step
         if (big_env == 4 && !linear) return launch_conv_t<T, 2, 2, 3, 5>(p, stream);
+#endif
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
         if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env);
@@ -1563,10 +1573,12 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     IM360_CHECK_ARG(M <= 0x7fffffffL, "linear_geglu: M too large");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
+#ifdef IM360_ABLATE
     if (knob(KNOB_CONV_BIG) == 3) {            // A/B: 128 x 256 tiles, two 4-wave workgroups per CU (one's GELU epilogue under the other's K loop)
         if (dtype == 0) return launch_conv_t<__bf16, 2, 2, 2, 4, 1>(p, s);
         if (dtype == 1) return launch_conv_t<_Float16, 2, 2, 2, 4, 1>(p, s);
     }
+#endif
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
         const int v = knob(KNOB_CONV_RING) >= 5 ? 1 : knob(KNOB_CONV_RING);
         if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);

@@ -79,6 +79,7 @@ class ResnetBlock3D(nn.Module):
         written."""
         pad = 2 if pano else 0
         if isinstance(x, (tuple, list)):
+            x = tuple(x)
             xa, xb = x
             if self.conv_shortcut is None or not kernels.can_conv1x1_cat(xa.shape[-1], xb.shape[-1]) or xb.shape[-1] % 8:
                 x = torch.cat([xa, xb], dim=-1)

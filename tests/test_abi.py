@@ -35,6 +35,56 @@ _SPILL_ALLOWED = ("temporal_attn_lds_kernel",                       # scalar fal
                   "Li64ELi4ELi1ELi2ELi2ELi0E")                      # 256 x 64 tile with 64-channel K steps (knob conv_small 1)
 
 
+# minimum waves per SIMD the registers of a default-path kernel must allow (gfx950: 512 registers per lane and SIMD, allocated
+# in granules of 8; VGPRs + AGPRs).  A kernel that silently grows past its step loses a third or half of its latency hiding --
+# hipcc only warns ("failed to meet occupancy target").  First match wins.
+_MIN_WAVES = (("attn_pipe_kernel", 2),
+              ("xattn_resident_kernel", 2),
+              (r"attn_fwd_kernelIDF16[b_]Li\d+ELi1E", 1),       # one-wave workgroups (<= 32 query rows): 16 staging chunks per lane
+              (r"attn_fwd_kernel.*Lb1EEEv", 3),                  # W3: one query block per wave at three waves per SIMD
+              (r"attn_fwd_kernelIDF16[b_]Li64ELi[24]ELi1ELb0ELb0ELb0ELb0ELb0ELb1E", 3),      # single-tile variant
+              ("attn_fwd_kernel", 2),
+              (r"conv_igemm_kernel.*Li2ELi2ELi3ELi5E", 1),        # (ablation builds only) four-wave 192 x 320 tile: the whole register file
+              ("conv_igemm_kernel", 2), ("conv_ring_kernel", 2), ("conv_halo_kernel", 2),
+              ("temporal_attn_mfma", 2))
+
+
+def test_default_path_kernels_keep_their_occupancy():
+    """Register budget of every MFMA kernel in the library against the occupancy it was designed for."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{tools}/llvm-objdump") and os.path.exists(f"{tools}/llvm-readelf")):
+        import pytest
+        pytest.skip("ROCm LLVM binutils not installed")
+    tmp = tempfile.mkdtemp()
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(os.path.join(ROOT, "imagine360_amd", "libim360_kernels.so"), so)
+        subprocess.run([f"{tools}/llvm-objdump", "--offloading", so], capture_output=True, cwd=tmp, check=True)
+        checked, bad = 0, []
+        for f in sorted(glob.glob(so + ".*gfx950")):
+            notes = subprocess.run([f"{tools}/llvm-readelf", "--notes", f], capture_output=True, text=True, check=True).stdout
+            for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", notes, re.S):
+                name, body = m.group(1), m.group(2)
+                regs = int(re.search(r"\.vgpr_count:\s+(\d+)", body).group(1))
+                ag = re.search(r"\.agpr_count:\s+(\d+)", body)
+                regs += int(ag.group(1)) if ag else 0
+                waves = min(8, 512 // max(8, (regs + 7) // 8 * 8))
+                for pat, want in _MIN_WAVES:
+                    if re.search(pat, name):
+                        checked += 1
+                        if waves < want:
+                            bad.append((name, regs, waves, want))
+                        break
+        assert checked >= 40, checked
+        assert not bad, bad
+    finally:
+        shutil.rmtree(tmp)
+
+
 def test_default_path_kernels_do_not_spill():
     """Per-kernel metadata of the gfx950 code objects inside the library (llvm-objdump --offloading + llvm-readelf --notes):
     at most 16 spilled VGPRs / 64 bytes of scratch outside the listed A/B variants."""

@@ -559,6 +559,8 @@ def test_conv3x3_chunk_major_k_order(dt, N, H, W, Cin, Cout, kw):
 def test_conv3x3_halo_patch_kernel(dt, N, H, W, Win, Cin, Cout, x_off):
     """The halo-patch kernel (knob conv_halo): rectangular pixel tiles, the (rows + 2) x (W + 2) input patch of a
     32-channel chunk in LDS once, nine taps out of it -- against the fp32 reference and against the streaming kernel."""
+    if not K.ablate_build():
+        pytest.skip("rejected A/B variant: only in `make ablate` builds of the library")
     g = torch.Generator().manual_seed(90)
     x = q16(torch.randn(N, H, Win, Cin, generator=g), dt)
     w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
@@ -782,6 +784,62 @@ def test_linear_with_folded_layer_norm(dt, M, C, N, frames, pixels, offset):
     e_f, e_u = rel(out, ref), rel(unf, ref)
     assert out.shape == (M, N) and e_f < TOL[dt] and blockrel(out, ref) < 2 * TOL[dt], (e_f, e_u)
     assert e_f < 1.5 * e_u + 1e-4, (e_f, e_u)            # no worse than normalising first (one 16-bit rounding fewer)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_linear_geglu_fused_large_magnitude_gates(dt):
+    """The fused GEGLU epilogue's transcendental-free GELU (gelu_poly_pk: Phi clamped at |x| = 4.2) on gate pre-activations
+    far outside the clamp: the result must tend to 0 for very negative gates -- round 3's form returned
+    x * 1.3e-5, i.e. grew linearly -- and to the value itself for very positive ones."""
+    M, Kd, I = 66000, 64, 128
+    g = torch.Generator().manual_seed(61)
+    x = q16(torch.randn(M, Kd, generator=g), dt)
+    w = q16(torch.randn(2 * I, Kd, generator=g) * Kd ** -0.5, dt)
+    b = torch.zeros(2 * I)
+    b[I:I + 32] = -30.0           # gates around -30 +- 1
+    b[I + 32:I + 64] = -6.0
+    b[I + 64:I + 96] = 25.0
+    b = q16(b, dt)
+    h = F.linear(x, w, b)
+    ref = h[:, :I] * F.gelu(h[:, I:])
+    wp, bp = K.pack_geglu(w.to(dt).cuda(), b.to(dt).cuda())
+    out = K.linear_geglu(x.to(dt).cuda(), wp, bp, I).float().cpu()
+    assert rel(out, ref) < TOL[dt]
+    # absolute error per gate band: |value| <= ~5, exact GELU(-30) = -0, GELU(-6) = -6e-9; the clamp leaves <= 5.6e-5 * |value|
+    assert (out[:, :32] - ref[:, :32]).abs().max() < 5e-4, (out[:, :32] - ref[:, :32]).abs().max()
+    assert (out[:, 32:64] - ref[:, 32:64]).abs().max() < 5e-4
+    assert rel(out[:, 64:96], ref[:, 64:96]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_linear_with_folded_layer_norm_rows_far_from_zero_mean(dt):
+    """the folded LayerNorm takes the variance as E[x^2] - mu^2 in fp32 from per-slice (sum, sum of squares): rows whose
+    mean is far larger than their spread (mean 50, std 0.5 -- about the largest ratio 16-bit storage of the rows can carry: a
+    bf16 value near 50 has a spacing of 0.25) lose digits there.  Bounded against fp32 torch.layer_norm on the STORED rows."""
+    from imagine360_amd import layers
+    M, C, N = 66000, 320, 960
+    g = torch.Generator().manual_seed(92)
+    saved = layers.ROUTE_MIN_TOKENS
+    layers.ROUTE_MIN_TOKENS = 0
+    try:
+        prod = torch.nn.Linear(C, C).to(dt).cuda()
+        with torch.no_grad():
+            prod.weight.mul_(0.02)
+            prod.bias.zero_()
+        x0 = torch.randn(M, C, generator=g).to(dt).cuda()
+        res = (50.0 + 0.5 * torch.randn(M, C, generator=g)).to(dt).cuda()
+        y, st = layers.gemm_linear(prod.weight, prod.bias, x0, res=res, cache=layers.DerivedCache(), row_stats=True)
+        norm = torch.nn.LayerNorm(C).to(dt).cuda()
+        w = (torch.randn(N, C, generator=g) * C ** -0.5).to(dt).cuda()
+        bias = (torch.randn(N, generator=g) * 0.1).to(dt).cuda()
+        out = layers.ln_linear(norm, w, bias, y, st, layers.DerivedCache(), "t")
+        unf = layers.ln_linear(norm, w, bias, y, None, layers.DerivedCache(), "t")
+    finally:
+        layers.ROUTE_MIN_TOKENS = saved
+    ref = F.linear(F.layer_norm(y.float(), (C,), norm.weight.float(), norm.bias.float(), norm.eps), w.float(), bias.float())
+    e_f, e_u = rel(out, ref), rel(unf, ref)
+    assert float(y.float().mean()) > 45 and float(y.float().std(dim=1).mean()) < 1.0
+    assert e_f < TOL[dt] and e_f < 1.5 * e_u + 5e-4, (e_f, e_u)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
