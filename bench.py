@@ -194,7 +194,7 @@ def _respawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -210,13 +210,19 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--warp-streams", type=int, default=1, help="with --dual-stream: the two directions of every WarpAttn on the two streams too")
     ap.add_argument("--dual-stream", type=int, default=1, help="1 (default): the panorama branch between WarpAttn calls on a side stream (two parallel branches in the hipGraph); 0: one stream")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: PLUMBING CHECK on CPU tensors (tests/test_dist_cpu.py): the rank bookkeeping, sharding, collectives and the JSON "
+                         "line of this script with whatever `imagine360_amd.kernels` the caller installed; never a benchmark number")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"),
                     help="rocprofv3 PMC summary (tools/hbm_traffic.sh) the roofline block quotes HBM traffic from")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
+    plumbing = args.backend == "gloo"
+    if plumbing:
+        args.cpu_baseline, args.no_graph, args.no_tuned_gemms = "none", True, True
 
-    if not torch.cuda.is_available():
+    if not plumbing and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn(args)
@@ -225,20 +231,29 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE {world}: the two must agree")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
+    if plumbing:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    dist, own_group, out = None, False, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        own_group = not dist.is_initialized()
+        if own_group:                          # (the CPU-tier test's harness has a gloo group up already)
+            if plumbing:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dt = torch.float32 if plumbing else (torch.bfloat16 if args.dtype == "bf16" else torch.float16)
     w = WORKLOADS[args.workload]
     frames = w["frames"]
     mode = args.parallelism if world > 1 else "samples"
     torch.set_grad_enabled(False)
-    kernels.lib()
+    if not plumbing:
+        kernels.lib()
     tuned = False
     from imagine360_amd import tuning
     if not args.no_tuned_gemms:
@@ -302,7 +317,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not plumbing:
+            torch.cuda.synchronize()
 
     prof_kinds = ["conv", "gemm", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
     graphed = None
@@ -351,7 +367,7 @@ def main():
     # per-kernel-class durations: the same K steps once more, issued eagerly with HIP events around every launch
     # of our kernels (a graph replay has no per-launch host hook); kernel durations do not depend on how they were launched
     eager_elapsed = None
-    if rank == 0 and shard is None:
+    if rank == 0 and shard is None and not plumbing:
         if graphed is not None:
             pano_lat, pers_lat = graphed.pano_lat.clone(), graphed.pers_lat.clone()
 
@@ -411,6 +427,7 @@ def main():
         samples = world if mode == "samples" else 1
         steps_per_s = samples * args.steps / elapsed
         out = {
+            **({"plumbing_check": True, "valid": False, "backend": "gloo (CPU tensors; NOT a benchmark: rank / shard / collective plumbing only)"} if plumbing else {}),
             "metric": "denoising steps/sec (dual-branch UNet, 16x512x1024 latent)",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -521,7 +538,9 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

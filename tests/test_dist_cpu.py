@@ -244,3 +244,65 @@ def test_frame_sharded_pipeline_call_matches_unsharded():
         assert out[r][0] < 1e-5 and out[r][1] < 1e-5, out[r]
         assert out[r][2] == 4 + 4 * 20 // 2, out[r]         # images through the VAE encoder: one 8-image chunk holds all 4 panorama frames; half of the 80 views
         assert out[r][3] and out[r][4], out[r]
+
+
+# ------------------------------------------------------------------ bench.py's own multi-rank plumbing
+def _bench_main(rank, world, mode):
+    import sys
+    import _emu_kernels as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    os.environ["LOCAL_RANK"] = str(rank)
+    with E.patched_kernels():
+        return bench.main(["--gpus", str(world), "--backend", "gloo", "--steps", "1", "--warmup", "1", "--workload", "cfg1",
+                           "--width-div", "10", "--parallelism", mode])
+
+
+def _bench_samples(rank, world):
+    return _bench_main(rank, world, "samples")
+
+
+def _bench_frames(rank, world):
+    return _bench_main(rank, world, "frames")
+
+
+def _bench_cfgxframes(rank, world):
+    return _bench_main(rank, world, "cfgxframes")
+
+
+@pytest.mark.parametrize("mode", ["samples", "frames", "cfgxframes"])
+def test_bench_script_runs_its_multi_rank_path_on_gloo(mode):
+    """`bench.py --gpus 2 --backend gloo`: the benchmark's OWN rank bookkeeping, input sharding, per-step exchanges, latent
+    gather, max-over-ranks timing and JSON line, on CPU tensors with the emulated kernels (a plumbing check, flagged invalid as
+    a measurement) -- so that the first run on a multi-GPU node does not also debut this code."""
+    out = _run({"samples": _bench_samples, "frames": _bench_frames, "cfgxframes": _bench_cfgxframes}[mode])
+    line = out[0]
+    assert out[1] is None and line is not None
+    assert line["plumbing_check"] is True and line["valid"] is False and line["n_gpus"] == 2
+    assert line["scaling"] == ("weak" if mode == "samples" else "strong") and line["steps"] == 1
+    assert line["value"] > 0 and line["config"]["outputs_finite"] is True
+    want = {"samples": "sample-parallel x2", "frames": "frame-chunk sharding x2 (4 frames per GPU)", "cfgxframes": "CFG halves x frame chunks (2 x 1)"}[mode]
+    assert line["config"]["parallelism"] == want
+
+
+def test_bench_script_respawn_command_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run on 127.0.0.1."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import argparse
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit) as e:
+        bench._respawn(argparse.Namespace(gpus=4))
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
