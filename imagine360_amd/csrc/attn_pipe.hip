@@ -53,7 +53,10 @@ template <int OFF> __device__ __forceinline__ void lds_read128(u32x4& dst, uint3
 template <int OFF> __device__ __forceinline__ void lds_read_tr64(u32x2& dst, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
 }
-template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+// (the builtin, not an asm statement: hipcc pads an asm statement that reads a register DEFINED BY ANOTHER asm statement with no
+//  compiler-visible instruction in between -- it cannot know what the first one was -- and the wait is such an instruction:
+//  26 -> 12 s_nop per tile.  Encoding: vmcnt = 63 and expcnt = 7 (no wait), lgkmcnt = N.)
+template <int N> __device__ __forceinline__ void wait_lgkm() { __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8)); }
 
 // ---- schedules: vector micro-ops issued after each of the 16 MFMA slots of a tile (softmax stream of 80, max stream of 16) ----
 // Constraints (checked at compile time): chunk q's 20 softmax ops precede PV slot 8 + 2 q; no max op before slot 10 (the
@@ -311,13 +314,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 // fragments of slot s are in; younger LDS operations: the reads of slots s + 1 .. s + AHEAD - 1 (the
                 // staging writes are older)
                 constexpr int younger = [] { int c = 0; for (int k = 1; k < AHEAD; ++k) c += (s + k >= 16 ? 0 : (s + k < 8 ? 1 : 2)); return c; }();
+                constexpr int v0 = sched_prefix(S.val, s), m0 = sched_prefix(S.mx, s);
+                // slot 0's vector work goes IN FRONT of its MFMA: it needs nothing from LDS, and the step's first fragment reads
+                // (issued right behind the barrier and the staging writes) are still in flight
+                if constexpr (s == 0) static_for<S.val[s]>([&](auto k) { vop(integral_constant<int, v0 + decltype(k)::value>{}, sc); });
                 if constexpr ((ABL & (8 | 128)) == 0) wait_lgkm<younger>();
                 if constexpr (s < 8) mm_qk(integral_constant<int, s>{}, sn);
                 else mm_pv(integral_constant<int, s - 8>{}, sc);
                 if constexpr (s + AHEAD < 8) rd_k(integral_constant<int, s + AHEAD>{}, KB{});
                 else if constexpr (s + AHEAD < 16) rd_v(integral_constant<int, s + AHEAD - 8>{}, VB{});
-                constexpr int v0 = sched_prefix(S.val, s), m0 = sched_prefix(S.mx, s);
-                static_for<S.val[s]>([&](auto k) { vop(integral_constant<int, v0 + decltype(k)::value>{}, sc); });
+                if constexpr (s != 0) static_for<S.val[s]>([&](auto k) { vop(integral_constant<int, v0 + decltype(k)::value>{}, sc); });
                 static_for<S.mx[s]>([&](auto k) { mop(integral_constant<int, m0 + decltype(k)::value>{}, sn); });
             });
             decide(sn, false);
