@@ -389,6 +389,8 @@ def main(argv=None):
     parity_check = None
     if rank == 0 and shard is None and graphed is not None:
         import random
+        saved_counters = (kernels.STATS, kernels.SHAPES)          # (the profile pass's per-launch flop / byte counters: not these steps')
+        kernels.STATS = kernels.SHAPES = None
         p0, q0 = graphed.pano_lat.clone(), graphed.pers_lat.clone()
         py_state, dev_state = random.getstate(), torch.cuda.get_rng_state(dev)
         i_chk = args.warmup + args.steps
@@ -417,6 +419,7 @@ def main(argv=None):
             "eager_two_streams_vs_one_rel": max(relf(res["eager_two_streams"][0], e_pano), relf(res["eager_two_streams"][1], e_pers)),
             "step_changed_the_latents_rel": relf(g_pano, p0),
         }
+        kernels.STATS, kernels.SHAPES = saved_counters
         if parity_check["graph_dual_vs_eager_rel"] > 1e-3:      # (bit-identical in practice; hipBLASLt may pick another solution under capture)
             raise SystemExit(f"bench.py: the benchmarked launch mode disagrees with the eager single-stream step: {parity_check}")
 

@@ -52,6 +52,11 @@ struct ConvParams {
     // persistent tile walk of the ring kernel: the cout tiles are split into `ngroups` groups, each walked by 8 / ngroups
     // XCDs over all pixel tiles (keeps one group's weights resident in those XCDs' L2s)
     int ngroups;
+    // GroupNorm statistics from the epilogue (GNS kernels, 256 x 320 tiles): per pixel tile and output channel (sum, sum of
+    // squares) of the values the tile stores, fp32 [M / 256][2][Cout] -- the layout of groupnorm.hip's per-slab partial sums
+    // when an image is a whole number of tiles (H W % 256 == 0: slab s of image n = tile n * (H W / 256) + s), so the consumer's
+    // GroupNorm skips its own statistics pass over the tensor (animatediff/models/resnet.py:221-243: norm -> act -> conv, twice)
+    float* gn_out;
 };
 
 // ConvParams with the optional members cleared
@@ -76,7 +81,7 @@ __device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v))
 // UP2: the tile's rows are pixels of the LOW-resolution grid [N, Hout, Wout]; row (n, y, x) is stored at pixel
 // (n, 2 y + up2_py, 2 x + up2_px) of the [N, 2 Hout, 2 Wout, Cout] output (sub-pixel form of nearest-x2 + conv3x3).
 // cvec (EPI 3 / 4): the tile's fp32 column vectors staged in LDS by the caller, [0, BN) = c1, [BN, 2 BN) = c2 (+ table row).
-template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false>
+template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
                                               int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0) {
     const int col = lane & 31, hi = lane >> 5;
@@ -209,6 +214,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         constexpr int PIECES = ROWB / 16;
         static_assert(ROWB == 128 || ROWB == 320, "swizzle pattern");
         static_assert((32 * PIECES) % 64 == 0, "store rounds cover the block exactly");
+        static_assert(!GNS || (!UP2 && EPI != 3), "GroupNorm statistics: plain conv / linear epilogues");
+        // GNS: every lane keeps ONE 16-byte piece (8 channels) through all store rounds -- RPR whole rows per round on
+        // RPR * PIECES lanes (60 of 64 at 320-byte rows: 11 rounds instead of 10) -- so that it can add up its channels'
+        // (sum, sum of squares) over the rows it stores in 16 registers
+        constexpr int RPR = 64 / PIECES;
+        float gsum[GNS ? 8 : 1], gsq[GNS ? 8 : 1];
+        if constexpr (GNS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gsum[e] = gsq[e] = 0.f;
+        }
         char* wlds = lds + wid_s * (32 * ROWB);
         const int fr = piece_xor(col, ROWB), br = (col >> 3) & 1;
         // Every global load of the epilogue is UNCONDITIONAL: an absent operand (no bias / temb / residual) reads the
@@ -261,12 +276,28 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
             // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
-            constexpr int NIT = (32 * PIECES) / 64, NIT1 = NIT / 2;
+            constexpr int NIT = GNS ? (32 + RPR - 1) / RPR : (32 * PIECES) / 64, NIT1 = NIT / 2;
             u32x4 rv[NIT];
+            // (row, piece) of this lane in store round `it`; false: the lane idles in this round (GNS only)
+            auto round_rc = [&](int it, int& row, int& pc) {
+                if constexpr (GNS) {
+                    row = it * RPR + lane / PIECES;
+                    pc = lane % PIECES;
+                    const bool act = lane < RPR * PIECES && row < 32;
+                    row = row < 32 ? row : 31;
+                    return act;
+                } else {
+                    const int f = it * 64 + lane;
+                    row = f / PIECES;
+                    pc = f % PIECES;
+                    return true;
+                }
+            };
             auto piece_off = [&](int it, bool& ok) {      // element offset of this lane's piece in round `it` (clamped into the block)
-                const int f = it * 64 + lane;
-                const int row = f / PIECES, co = nw0 + (f % PIECES) * 8;
-                ok = row < rows && co < p.Cout;
+                int row, pc;
+                const bool act = round_rc(it, row, pc);
+                const int co = nw0 + pc * 8;
+                ok = act && row < rows && co < p.Cout;
                 return (uint32_t)((row < rows ? row : rows - 1) * p.Cout + (co < cmax8 ? co : cmax8));
             };
             auto load_res = [&](int it0, int it1) {
@@ -332,18 +363,31 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int f = it * 64 + lane;
-                const int row = f / PIECES, pc = f % PIECES;
+                int row, pc;
+                const bool act = round_rc(it, row, pc);
                 uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
                 if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
                 const u32x4 w = rv[it];
-                o.x = pack2<T>(unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x));
-                o.y = pack2<T>(unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y));
-                o.z = pack2<T>(unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z));
-                o.w = pack2<T>(unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w));
+                float fv[8] = {unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x), unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y),
+                               unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z), unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w)};
+                o.x = pack2<T>(fv[0], fv[1]);
+                o.y = pack2<T>(fv[2], fv[3]);
+                o.z = pack2<T>(fv[4], fv[5]);
+                o.w = pack2<T>(fv[6], fv[7]);
                 bool ok;
                 const uint32_t off = piece_off(it, ok);
-                if constexpr (EPI == 5) {
+                if constexpr (GNS) {
+                    // statistics of the values as STORED (rounded to 16 bits: what a statistics pass over the tensor would read)
+                    const float wgt = ok ? 1.f : 0.f;
+                    const float sv[8] = {unpack_lo<T>(o.x), unpack_hi<T>(o.x), unpack_lo<T>(o.y), unpack_hi<T>(o.y), unpack_lo<T>(o.z), unpack_hi<T>(o.z), unpack_lo<T>(o.w), unpack_hi<T>(o.w)};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = wgt * sv[e];
+                        gsum[e] += v;
+                        gsq[e] = fmaf(v, sv[e], gsq[e]);
+                    }
+                }
+                if (EPI == 5 && (!GNS || act)) {
                     // row statistics of the STORED values (what a LayerNorm of this tensor would read): this piece's
                     // (sum, sum of squares) parked in its own staging slot, collected per row after the store rounds
                     float ss = 0.f, qq = 0.f;
@@ -354,8 +398,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     *(f32x2*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4)) = f32x2{ss, qq};
                 }
                 if constexpr (UP2) {
-                    const int f = it * 64 + lane;
-                    const int row = f / PIECES, co = nw0 + (f % PIECES) * 8;
+                    const int co = nw0 + pc * 8;
                     const long mrow = mb + (row < rows ? row : rows - 1);
                     const long nimg = mrow / hw;
                     const int rem = (int)(mrow - nimg * hw);
@@ -387,6 +430,38 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
+        }
+        if constexpr (GNS) {
+            // this wave's staging rows are free: park the lane's 16 sums there ([lane][16] floats), then -- after a workgroup
+            // barrier -- thread c of the tile adds up channel c over the waves that stored its rows (same wn, every wm) and
+            // the RPR row-lanes of each, in a fixed order (deterministic), and writes the tile's (sum, sum of squares)
+            float* st = (float*)wlds;
+            if (lane < RPR * PIECES) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    st[lane * 16 + e] = gsum[e];
+                    st[lane * 16 + 8 + e] = gsq[e];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            constexpr int WM_ = NT / 64 / WN_, BNT = WN_ * TN * 32;
+            const int c = wid_s * 64 + lane;
+            if (c < BNT && n0 + c < p.Cout) {
+                const int wn_c = c / (TN * 32), chunk = (c % (TN * 32)) / 8, e = c % 8;
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM_; ++m)
+#pragma unroll
+                    for (int r = 0; r < RPR; ++r) {
+                        const float* src = (const float*)(lds + (m * WN_ + wn_c) * (32 * ROWB)) + (r * PIECES + chunk) * 16;
+                        ss += src[e];
+                        qq += src[8 + e];
+                    }
+                constexpr int BM_ = WM_ * TM * 32;
+                float* dst = p.gn_out + (m0 / BM_) * 2 * (long)p.Cout + n0 + c;
+                dst[0] = ss;
+                dst[p.Cout] = qq;
+            }
         }
         return;
     }
@@ -437,7 +512,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // UP2 (4 taps): one output parity of nearest-x2-upsample + conv3x3 as a 2 x 2 convolution of the low-resolution input with
 // pre-summed weights (after the upsample every output parity sees only 2 x 2 distinct source pixels): tap (r, c) reads
 // source pixel (y + r + py - 1, x + c + px - 1); 4 / 9 of the MACs of the upsampled form.
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false>
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false, bool GNS = false>
 // (waves per SIMD given as min AND max: with the minimum alone hipcc aimed the 256 x 64 tile at three waves per SIMD -- 168 registers --
 //  and spilled 688 bytes inside the K loop once ConvParams grew in round 3: 1.58 ms instead of 0.25 ms for a cfg1-sized 320 -> 320
 //  convolution; its LDS footprint allows two workgroups per CU anyway)
@@ -684,7 +759,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     static_assert((NT / 64) * 32 * ((EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
-    tile_epilogue<T, NT, TM, TN, EPI, false, UP2>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
+    tile_epilogue<T, NT, TM, TN, EPI, false, UP2, GNS, WN>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
 
 // ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
@@ -699,7 +774,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 //     slots 2 / 3), so the operand stream keeps flowing while accumulators are converted and stored.
 // Accumulation order over K is the same as in the kernel above (16 channels per MFMA, ascending), so results are
 // bit-identical.
-template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE>
+template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool GNS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
     constexpr int BM = 256, BN = WN * TN * 32, BK = 32;
@@ -1069,7 +1144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
         if (next >= ntiles) break;
         tile = next;
     }
@@ -1330,6 +1405,18 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         }
     }
 #endif
+    if constexpr (WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0) {
+        if (p.gn_out) {            // the 256 x 320 tile with GroupNorm statistics from its epilogue
+            if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if (p.gn_out) {
+        im360_set_error("conv_fwd: GroupNorm statistics are produced by the 256 x 320 tile only (ask im360_conv_gn_slabs first)");
+        return IM360_ERR_UNSUPPORTED;
+    }
     if (cm) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
@@ -1372,6 +1459,17 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     }
     // variant (knob conv_ring): 1 = asm LDS-DMA, pieces interleaved with the MFMAs (default); 2 = builtin LDS-DMA, plain ring;
     // 3 = asm LDS-DMA, plain ring; 4 = asm LDS-DMA, staggered wave groups
+    if constexpr (LINEAR && TN == 5 && (EPI == 2 || EPI == 5)) {
+        if (p.gn_out) {                         // GroupNorm partial sums from the epilogue (see ConvParams::gn_out)
+            hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2, true>), dim3(grid), dim3(512), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if (p.gn_out) {
+        im360_set_error("linear_fwd: GroupNorm statistics are produced by the plain / row-statistics epilogues only");
+        return IM360_ERR_UNSUPPORTED;
+    }
     if constexpr (EPI >= 3) {                   // LayerNorm-folded / statistics-writing epilogues: the default pipeline only
         hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     } else {
@@ -1440,6 +1538,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 #endif
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
+        if (p.gn_out && !linear) return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
         if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env);
         if (ring_env >= 5) return launch_ring_t<T, 5, 0, false>(p, stream, 1);
         if (linear) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
@@ -1476,14 +1575,27 @@ __global__ void pack_conv_weight_kernel(const T* __restrict__ w, T* __restrict__
 
 }  // namespace im360
 
+// Slabs per image of the GroupNorm partial sums a conv / token-major linear launch of these dimensions can write from its
+// epilogue (gn_partial: fp32 [N * S][2][Cout]), or 0 when it cannot: needs the 256 x 320 tile (Cout % 320 == 0, Cin % 64 == 0,
+// at least 512 tiles) and images that are whole numbers of 256-pixel tiles.  For a linear, pass the [N, Hout, Wout] image
+// shape of its token rows and ntaps = 1.
+extern "C" int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps) {
+    using namespace im360;
+    const int64_t hw = Hout * Wout, M = N * hw;
+    if (N <= 0 || hw <= 0 || (hw % 256) != 0 || (Cout % 320) != 0 || (Cin % 64) != 0 || (ntaps != 1 && ntaps != 9)) return 0;
+    if (!knob(KNOB_CONV_BIG) || (M / 256) * (Cout / 320) < 512) return 0;
+    return hw / 256;
+}
+
 extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
                               const void* res, void* y,
                               int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
                               int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
                               int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
-                              int64_t imgs_per_temb, int dtype, void* stream) {
+                              int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "conv_fwd: null pointer");
+    IM360_CHECK_ARG(!gn_partial || (im360_conv_gn_slabs(N, Hout, Wout, Cin, Cout, ntaps) > 0 && !up), "conv_fwd: this launch cannot produce GroupNorm statistics (im360_conv_gn_slabs == 0)");
     IM360_CHECK_ARG(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cout > 0, "conv_fwd: empty problem");
     IM360_CHECK_ARG(Cin > 0 && (Cin % 32) == 0, "conv_fwd: Cin=%ld must be a multiple of 32 (pad channels)", (long)Cin);
     IM360_CHECK_ARG(ntaps == 9 || ntaps == 1, "conv_fwd: ntaps must be 9 or 1");
@@ -1501,6 +1613,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
     p.stride = (int)stride; p.up = up ? 1 : 0; p.wrap = wrap ? 1 : 0; p.x_off = (int)x_off; p.y_off = (int)y_off;
     p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
     p.M = N * Hout * Wout;
+    p.gn_out = (float*)gn_partial;
     hipStream_t s = (hipStream_t)stream;
     // token-major linears routed through the kernel (1x1 taps on a [M, 1, 1, K] view) are accounted separately
     ProfScope prof(ntaps == 1 && Hin == 1 && Win == 1 ? PROF_GEMM : PROF_CONV, stream);
@@ -1620,7 +1733,7 @@ extern "C" int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void*
 // (im360_linear_ln_fwd / im360_linear_geglu_ln) and the LayerNorm pass over the activations disappears.
 // Replaces: nn.Linear + residual add feeding nn.LayerNorm, animatediff/models/attention.py:461-508, motion_module.py:230-258.
 extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y,
-                                void* rowstats, int64_t M, int64_t K, int64_t N, int dtype, void* stream) {
+                                void* rowstats, int64_t M, int64_t K, int64_t N, int dtype, void* stream, void* gn_partial) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "linear_fwd: null pointer");
     IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_fwd: K=%ld must be a positive multiple of 32", (long)K);
@@ -1633,6 +1746,8 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     p.N = (int)M; p.Hin = 1; p.Win = 1; p.Cin = (int)K; p.Hout = 1; p.Wout = 1; p.Cout = (int)N; p.ntaps = 1;
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
+    IM360_CHECK_ARG(!gn_partial || ((M % 256) == 0 && (K % 64) == 0), "linear_fwd: GroupNorm statistics need M %% 256 == 0 and K %% 64 == 0");
+    p.gn_out = (float*)gn_partial;          // (per 256-row tile: the caller's images are whole numbers of tiles)
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
     const int v = knob(KNOB_CONV_RING) >= 1 && knob(KNOB_CONV_RING) <= 4 ? knob(KNOB_CONV_RING) : 1;

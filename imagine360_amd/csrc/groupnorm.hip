@@ -121,6 +121,49 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// The same from partial sums that need not come from gn_partial_kernel: the channels [0, C1) from `pa` (Sa slabs per image,
+// [n][s][2][C1]) and [C1, C1 + C2) from `pb` (Sb slabs, [n][s][2][C2]) -- either buffer may have been written by the epilogue
+// of the convolution / linear that produced that tensor (ConvParams::gn_out: one slab per 256-pixel tile).
+template <typename T>
+__global__ __launch_bounds__(64) void gn_finalize2_kernel(const float* __restrict__ pa, int Sa, int C1, const float* __restrict__ pb, int Sb, int C2,
+                                                          const T* __restrict__ gamma, const T* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int G, double count, float eps) {
+    const int C = C1 + C2;
+    const int n = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
+    const int cpg = C / G;
+    double sum = 0.0, sq = 0.0;
+    // channels of this group in the first / second source
+    const int c0 = g * cpg, c1 = c0 + cpg;
+    const int a0 = c0 < C1 ? c0 : C1, a1 = c1 < C1 ? c1 : C1;          // [a0, a1) in source a
+    const int b0 = (c0 > C1 ? c0 : C1) - C1, b1 = (c1 > C1 ? c1 : C1) - C1;      // [b0, b1) in source b
+    const int na = a1 - a0, nb = b1 - b0;
+    for (int i = lane; i < Sa * na; i += 64) {
+        const float* src = pa + ((long)n * Sa + i / na) * 2 * C1 + a0 + i % na;
+        sum += (double)src[0];
+        sq += (double)src[C1];
+    }
+    for (int i = lane; i < Sb * nb; i += 64) {
+        const float* src = pb + ((long)n * Sb + i / nb) * 2 * C2 + b0 + i % nb;
+        sum += (double)src[0];
+        sq += (double)src[C2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        sq += __shfl_xor(sq, o);
+    }
+    const double mean = sum / count;
+    double var = sq / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    for (int j = lane; j < cpg; j += 64) {
+        const int c = c0 + j;
+        const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
+        scale[(long)n * C + c] = (float)(rstd * ga);
+        shift[(long)n * C + c] = (float)(be - mean * rstd * ga);
+    }
+}
+
 // ---- pass 3 -----------------------------------------------------------------------------------
 // grid (S, N).  out[n][y][x'][c] = act(x[n][y][(x' - pad) mod W][c] * scale[n][c] + shift[n][c]),
 // x' in [0, W + 2 pad)
@@ -480,6 +523,41 @@ extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const voi
     ProfScope prof(PROF_GN_STATS, stream);
     if (dtype == 0) launch_gn_stats<__bf16>(x, nullptr, C, 0, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
     else launch_gn_stats<_Float16>(x, nullptr, C, 0, gamma, beta, partial, scale, shift, N, H, W, G, pad, eps, (hipStream_t)stream);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// Per-slab partial sums only (no finalize, no pad weighting): partial fp32 [N][S][2][C], S = im360_gn_num_slabs(N, H, W).
+extern "C" int im360_groupnorm_partial(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && partial, "groupnorm_partial: null pointer");
+    IM360_CHECK_ARG(N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "groupnorm_partial: bad shape");
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0, "groupnorm_partial: misaligned x");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_partial: dtype %d unsupported", dtype);
+    ProfScope prof(PROF_GN_STATS, stream);
+    const int S = pick_slabs(N, H * W);
+    if (dtype == 0) hipLaunchKernelGGL((gn_partial_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (float*)partial, (int)(H * W), (int)W, (int)C, 0, S, (int)C, 0);
+    else hipLaunchKernelGGL((gn_partial_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (float*)partial, (int)(H * W), (int)W, (int)C, 0, S, (int)C, 0);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// scale / shift [N, C1 + C2] from partial sums: channels [0, C1) from pa ([N][Sa][2][C1]), [C1, C1 + C2) from pb ([N][Sb][2][C2];
+// pb may be null with C2 = 0).  The partial sums come from im360_groupnorm_partial or from the epilogue of the kernel that
+// produced the tensor (im360_conv_fwd / im360_linear_fwd, gn_partial).  count = H * W pixels per image.
+extern "C" int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, const void* pb, int64_t Sb, int64_t C2, const void* gamma,
+                                        const void* beta, void* scale, void* shift, int64_t N, int64_t G, int64_t pixels, float eps,
+                                        int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(pa && gamma && beta && scale && shift && (pb || C2 == 0), "groupnorm_finalize: null pointer");
+    IM360_CHECK_ARG(N > 0 && G > 0 && C1 > 0 && C2 >= 0 && Sa > 0 && (C2 == 0 || Sb > 0) && pixels > 0 && ((C1 + C2) % G) == 0, "groupnorm_finalize: bad shape");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_finalize: dtype %d unsupported", dtype);
+    ProfScope prof(PROF_GN_STATS, stream);
+    const double count = (double)pixels * (double)((C1 + C2) / G);
+    if (dtype == 0) hipLaunchKernelGGL((gn_finalize2_kernel<__bf16>), dim3((unsigned)(N * G)), dim3(64), 0, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
+                                       (const __bf16*)gamma, (const __bf16*)beta, (float*)scale, (float*)shift, (int)G, count, eps);
+    else hipLaunchKernelGGL((gn_finalize2_kernel<_Float16>), dim3((unsigned)(N * G)), dim3(64), 0, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
+                            (const _Float16*)gamma, (const _Float16*)beta, (float*)scale, (float*)shift, (int)G, count, eps);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -29,10 +29,13 @@ _SIGNATURES = {
     "im360_groupnorm_fused": (_INT, [_PTR] * 7 + [_I64] * 7 + [_F32, _INT, _INT, _PTR]),
     "im360_groupnorm_apply_cat": (_INT, [_PTR] * 5 + [_I64] * 6 + [_INT, _INT, _PTR]),
     "im360_conv1x1_cat_fwd": (_INT, [_PTR] * 6 + [_I64] * 6 + [_INT, _PTR]),
-    "im360_linear_fwd": (_INT, [_PTR] * 6 + [_I64] * 3 + [_INT, _PTR]),
+    "im360_linear_fwd": (_INT, [_PTR] * 6 + [_I64] * 3 + [_INT, _PTR, _PTR]),
     "im360_linear_ln_fwd": (_INT, [_PTR] * 5 + [_I64, _F32, _PTR, _I64, _I64, _PTR] + [_I64] * 3 + [_INT, _PTR]),
     "im360_linear_geglu_ln": (_INT, [_PTR] * 5 + [_I64, _F32, _PTR] + [_I64] * 3 + [_INT, _PTR]),
-    "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR]),
+    "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR, _PTR]),
+    "im360_conv_gn_slabs": (_I64, [_I64] * 6),
+    "im360_groupnorm_partial": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
+    "im360_groupnorm_finalize": (_INT, [_PTR, _I64, _I64, _PTR, _I64, _I64] + [_PTR] * 4 + [_I64] * 3 + [_F32, _INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
     "im360_conv_up2_fwd": (_INT, [_PTR] * 4 + [_I64] * 6 + [_INT, _PTR]),
@@ -233,6 +236,33 @@ def shard_pack(src, dst, B, Fl, P, W, PP, unpack=False):
 
 
 # ------------------------------------------------------------------------------------------ group norm
+# GroupNorm statistics from the producer's epilogue: conv2d(..., gn_stats=True) / linear(..., gn_hw=pixels)
+# attach `(partial sums, slabs per image)` to the tensor they return when the launch can write them (im360_conv_gn_slabs);
+# group_norm_stats() then skips its own pass over that tensor.  The tag belongs to the tensor OBJECT and dies with a view /
+# reshape (carry_gn moves it onto a reshaped view of the same rows) or an in-place write (checked through _version).
+GN_FROM_PRODUCER = True
+
+
+def _gn_of(t):
+    g = getattr(t, "_im360_gn", None)
+    if g is None or g[2] != t._version:
+        return None
+    return g[0], g[1]
+
+
+def _tag_gn(t, partial, slabs):
+    t._im360_gn = (partial, slabs, t._version)
+    return t
+
+
+def carry_gn(view, src):
+    """``view`` is a reshape of ``src`` with the same rows (tokens [n, hw, c] <-> images [n, h, w, c]): keep the producer's partial sums."""
+    g = getattr(src, "_im360_gn", None)
+    if g is not None and g[2] == src._version and view.numel() == src.numel():
+        view._im360_gn = (g[0], g[1], view._version)
+    return view
+
+
 def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
     """x [N, H, W, C] channels-last, or a pair (xa [N, H, W, C1], xb [N, H, W, C2]) standing for their channel
     concatenation (never materialised).  Returns fp32 (scale, shift) [N, C] with GN(x) = x*scale + shift;
@@ -242,10 +272,31 @@ def group_norm_stats(x, gamma, beta, groups, eps, pad=0):
     N, H, W, C1 = xa.shape
     C = C1 + (xb.shape[-1] if xb is not None else 0)
     assert xa.is_contiguous() and gamma.dtype == xa.dtype and beta.dtype == xa.dtype and gamma.numel() == C
-    S = lib().im360_gn_num_slabs(N, H, W)
-    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=xa.device)
     scale = torch.empty((N, C), dtype=torch.float32, device=xa.device)
     shift = torch.empty((N, C), dtype=torch.float32, device=xa.device)
+    srcs = [xa] if xb is None else [xa, xb]
+    if pad == 0 and GN_FROM_PRODUCER and any(_gn_of(t) is not None for t in srcs):
+        # at least one source carries partial sums from the epilogue of the kernel that produced it (conv2d / linear with
+        # gn_stats): only the others get a statistics pass, then one finalize over both sets of partial sums
+        parts, read = [], 0
+        for t in srcs:
+            g = _gn_of(t)
+            if g is None:
+                St = lib().im360_gn_num_slabs(N, H, W)
+                buf = torch.empty((N * St * 2 * t.shape[-1],), dtype=torch.float32, device=t.device)
+                assert t.is_contiguous() and t.shape[:3] == xa.shape[:3] and t.dtype == xa.dtype
+                _check(lib().im360_groupnorm_partial(_p(t), _p(buf), N, H, W, t.shape[-1], _dt(t), _stream()), "im360_groupnorm_partial")
+                g = (buf, St)
+                read += t.element_size() * t.numel()
+            parts.append(g)
+        (pa, Sa), (pb, Sb) = parts[0], (parts[1] if len(parts) > 1 else (None, 0))
+        rc = lib().im360_groupnorm_finalize(_p(pa), Sa, C1, _p(pb), Sb, C - C1, _p(gamma), _p(beta), _p(scale), _p(shift), N, groups,
+                                            H * W, float(eps), _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_finalize")
+        _count("gn_stats", 0.0, read + 4 * sum(p_.numel() for p_, _ in parts))
+        return scale, shift
+    S = lib().im360_gn_num_slabs(N, H, W)
+    partial = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=xa.device)
     if xb is None:
         rc = lib().im360_groupnorm_stats(_p(xa), _p(gamma), _p(beta), _p(partial), _p(scale), _p(shift),
                                          N, H, W, C, groups, pad, float(eps), _dt(xa), _stream())
@@ -364,7 +415,7 @@ def conv_up2(x, w4_packed, cout, bias=None, wrap=False):
 
 
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None,
-           temb=None, imgs_per_temb=1, res=None, y_off=0):
+           temb=None, imgs_per_temb=1, res=None, y_off=0, gn_stats=False):
     """x [N, Hin, Win, Cin] -> y [N, Hout, Wout, Cout] (3x3 pad 1 or 1x1, see im360_conv_fwd)."""
     _dev(x, w_packed, bias, temb, res)
     N, Hin, Win, Cin = x.shape
@@ -379,10 +430,17 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
         assert res.shape == y.shape and res.is_contiguous()
     if temb is not None:
         assert temb.is_contiguous() and temb.shape[1] == cout and temb.shape[0] * imgs_per_temb == N
+    gn, slabs = None, 0
+    if gn_stats and GN_FROM_PRODUCER and not up:
+        slabs = lib().im360_conv_gn_slabs(N, hout, wout, Cin, cout, taps)
+        if slabs > 0:
+            gn = torch.empty((N * slabs * 2 * cout,), dtype=torch.float32, device=x.device)
     rc = lib().im360_conv_fwd(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
                               N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
-                              imgs_per_temb, _dt(x), _stream())
+                              imgs_per_temb, _dt(x), _stream(), _p(gn))
     _check(rc, "im360_conv_fwd")
+    if gn is not None:
+        _tag_gn(y, gn, slabs)
     if STATS is not None or SHAPES is not None:
         es = x.element_size()
         linear = taps == 1 and Hin == 1 and Win == 1
@@ -420,7 +478,7 @@ def conv1x1_cat(xa, xb, w_packed, cout, bias=None, res=None):
 ROW_SLICE = 160          # columns per (sum, sum of squares) pair of the row statistics (one wave's share of a 320-column tile)
 
 
-def linear(x, w_packed, n, bias=None, res=None, row_stats=False):
+def linear(x, w_packed, n, bias=None, res=None, row_stats=False, gn_hw=None):
     """x [..., K] @ W^T + bias (+ res) -> [..., n] on the persistent ring kernel (n % 320 == 0, K % 32 == 0; w_packed from
     ``pack_conv_weight`` of the [n, K, 1, 1] view).  ``row_stats``: also return fp32 [M, n / 160, 2] = per row and
     160-column slice (sum, sum of squares) of the stored output -- the LayerNorm statistics a consumer with the
@@ -432,8 +490,15 @@ def linear(x, w_packed, n, bias=None, res=None, row_stats=False):
     y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
     assert res is None or (res.is_contiguous() and res.numel() == y.numel() and res.dtype == x.dtype)
     st = torch.empty((m, n // ROW_SLICE, 2), dtype=torch.float32, device=x.device) if row_stats else None
-    rc = lib().im360_linear_fwd(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), _p(st), m, k, n, _dt(x), _stream())
+    # gn_hw: the rows are images of gn_hw pixels each; when those are whole 256-row tiles the epilogue also writes GroupNorm
+    # partial sums (one slab per tile) for the consumer's GroupNorm
+    gn = None
+    if gn_hw and GN_FROM_PRODUCER and gn_hw % 256 == 0 and m % gn_hw == 0 and k % 64 == 0:
+        gn = torch.empty(((m // 256) * 2 * n,), dtype=torch.float32, device=x.device)
+    rc = lib().im360_linear_fwd(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), _p(st), m, k, n, _dt(x), _stream(), _p(gn))
     _check(rc, "im360_linear_fwd")
+    if gn is not None:
+        _tag_gn(y, gn, gn_hw // 256)
     _count("gemm", 2.0 * m * k * n, x.element_size() * (x.numel() + n * k + y.numel() * (2 if res is not None else 1))
            + (0 if st is None else 4 * st.numel()), shape=f"lin{'+stats' if row_stats else ''}:{k}:{n}:{'res' if res is not None else 'nores'}")
     return (y, st) if row_stats else y

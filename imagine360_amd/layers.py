@@ -77,7 +77,7 @@ class InflatedConv3d(nn.Conv2d):
     def cin_padded(self):
         return ((self.in_channels + 31) // 32) * 32
 
-    def forward_cl(self, x, wrap=False, up=False, x_off=0, wout=None, temb=None, imgs_per_temb=1, res=None, y_off=0):
+    def forward_cl(self, x, wrap=False, up=False, x_off=0, wout=None, temb=None, imgs_per_temb=1, res=None, y_off=0, gn_stats=False):
         """x [N, H, W, Cin(+zero pad to a multiple of 32)] channels-last."""
         if x.shape[-1] != self.cin_padded:
             x = F.pad(x, (0, self.cin_padded - x.shape[-1]))
@@ -88,7 +88,7 @@ class InflatedConv3d(nn.Conv2d):
             return kernels.conv_up2(x, w4, self.out_channels, bias=self.bias, wrap=wrap)
         return kernels.conv2d(x, self.packed_weight(), self.out_channels, bias=self.bias, stride=self.stride[0],
                               up=up, wrap=wrap, x_off=x_off, wout=wout, temb=temb, imgs_per_temb=imgs_per_temb,
-                              res=res, y_off=y_off)
+                              res=res, y_off=y_off, gn_stats=gn_stats)
 
     def forward_cat(self, xa, xb, res=None):
         """1x1 convolution of the channel concatenation [xa | xb] without materialising it (the decoder's conv_shortcut)."""
@@ -140,7 +140,7 @@ def _routed(x, m, k, n):
     return (x.is_cuda or ROUTE_ON_CPU) and _gemm_kernel_pays(m, k, n)
 
 
-def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1", row_stats=False):
+def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1", row_stats=False, gn_hw=None):
     """``x @ weight.T + bias (+ res)``.  Large token counts: one launch of the MFMA implicit-GEMM kernel (as a 1x1
     conv over a [M, 1, 1, K] view) with bias and residual in its epilogue -- no separate elementwise pass over the
     activations; otherwise hipBLASLt (+ an add).  ``cache``: DerivedCache holding the packed weight.
@@ -155,6 +155,9 @@ def gemm_linear(weight, bias, x, res=None, cache=None, key="w1x1", row_stats=Fal
     wp = cache.get(key, (weight,), lambda: kernels.pack_conv_weight(weight.detach().reshape(n, k, 1, 1)))
     if row_stats:
         return kernels.linear(x.contiguous(), wp, n, bias=bias, res=None if res is None else res.contiguous(), row_stats=True)
+    if gn_hw:
+        # the consumer is a GroupNorm over images of gn_hw tokens: its partial sums come out of this launch's epilogue
+        return kernels.linear(x.contiguous(), wp, n, bias=bias, res=None if res is None else res.contiguous(), gn_hw=gn_hw)
     r4 = None if res is None else res.contiguous().reshape(m, 1, 1, n)
     y = kernels.conv2d(x.contiguous().reshape(m, 1, 1, k), wp, n, bias=bias, res=r4)
     return y.reshape(*x.shape[:-1], n)
@@ -190,9 +193,9 @@ def linear(lin, x, row_stats=False):
     return gemm_linear(lin.weight, lin.bias, x, cache=_module_cache(lin), row_stats=row_stats)
 
 
-def linear_residual(lin, x, res, row_stats=False):
+def linear_residual(lin, x, res, row_stats=False, gn_hw=None):
     """``lin(x) + res`` through ``gemm_linear``."""
-    return gemm_linear(lin.weight, lin.bias, x, res=res, cache=_module_cache(lin), row_stats=row_stats)
+    return gemm_linear(lin.weight, lin.bias, x, res=res, cache=_module_cache(lin), row_stats=row_stats, gn_hw=gn_hw)
 
 
 class GEGLU(nn.Module):

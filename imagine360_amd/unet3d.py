@@ -86,13 +86,15 @@ class ResnetBlock3D(nn.Module):
         w = (x[0] if isinstance(x, tuple) else x).shape[2]
         h = self.norm1.forward_cl(x, silu=True, pad=pad)
         t = self.time_emb_proj(F.silu(temb)).contiguous() if (temb is not None and self.time_emb_proj is not None) else None
-        h = self.conv1.forward_cl(h, temb=t, imgs_per_temb=frames)
+        # (gn_stats: the convolution's epilogue leaves the GroupNorm partial sums of what it stores for the next norm --
+        #  resnet.py:221-243 is norm -> SiLU -> conv twice, and every module that follows opens with a GroupNorm)
+        h = self.conv1.forward_cl(h, temb=t, imgs_per_temb=frames, gn_stats=True)
         h = self.norm2.forward_cl(h, silu=True)
         if isinstance(x, tuple):
             short = self.conv_shortcut.forward_cat(*x)
         else:
             short = x if self.conv_shortcut is None else self.conv_shortcut.forward_cl(x)
-        return self.conv2.forward_cl(h, x_off=pad, wout=w, res=short)
+        return self.conv2.forward_cl(h, x_off=pad, wout=w, res=short, gn_stats=True)
 
     def forward(self, input_tensor, temb):
         x, f = to_cl(input_tensor)
@@ -240,7 +242,8 @@ class Transformer3DModel(nn.Module):
         for blk in self.transformer_blocks:
             y = blk(y, ctx, frames=frames, stats=st)
             st = None
-        return linear_residual(self.proj_out, y, x.reshape(n, h * w, c)).reshape(n, h, w, c)
+        out = linear_residual(self.proj_out, y, x.reshape(n, h * w, c), gn_hw=h * w)
+        return kernels.carry_gn(out.reshape(n, h, w, c), out)
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
         x, f = to_cl(hidden_states)
@@ -345,7 +348,8 @@ class TemporalTransformer3DModel(nn.Module):
         for blk in self.transformer_blocks:
             y = blk(y, n // frames, frames, h * w, stats=st)
             st = None
-        return linear_residual(self.proj_out, y, x.reshape(n * h * w, c)).reshape(n, h, w, c)
+        out = linear_residual(self.proj_out, y, x.reshape(n * h * w, c), gn_hw=h * w)
+        return kernels.carry_gn(out.reshape(n, h, w, c), out)
 
 
 class VanillaTemporalModule(nn.Module):

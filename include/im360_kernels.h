@@ -93,6 +93,14 @@ int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, vo
 /* y[N, H, W + 2 pad, C] = act(x * scale + shift) with circular W addressing; act 0 = none, 1 = SiLU.
  * Replaces: the normalise + F.silu pass (resnet.py:224-225, 236-243) fused with pad_pano
  *   (src/utils/pano.py:75-95). */
+/* Partial sums only: partial fp32 [N][S][2][C], S = im360_gn_num_slabs(N, H, W) (no pad weighting). */
+int im360_groupnorm_partial(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream);
+/* scale / shift [N, C1 + C2] from partial sums of one or two channel ranges: [0, C1) from pa ([N][Sa][2][C1]), [C1, C1 + C2)
+ * from pb ([N][Sb][2][C2], null with C2 = 0).  Either may come from im360_groupnorm_partial or from the epilogue of the
+ * kernel that produced that tensor (gn_partial of im360_conv_fwd / im360_linear_fwd).  pixels = H * W per image. */
+int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, const void* pb, int64_t Sb, int64_t C2, const void* gamma,
+                             const void* beta, void* scale, void* shift, int64_t N, int64_t G, int64_t pixels, float eps,
+                             int dtype, void* stream);
 int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
                           int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
                           int dtype, void* stream);
@@ -131,7 +139,13 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
                    int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
                    int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
                    int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
-                   int64_t imgs_per_temb, int dtype, void* stream);
+                   int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial);
+/* gn_partial (optional; last argument of im360_conv_fwd / im360_linear_fwd): the epilogue also writes per 256-pixel tile and
+ * output channel (sum, sum of squares) of the stored values, fp32 [M / 256][2][Cout] -- GroupNorm partial sums with one slab
+ * per tile, consumed by im360_groupnorm_finalize in place of a statistics pass over the tensor
+ * (animatediff/models/resnet.py:221-243 is norm -> SiLU -> conv twice).  Only launches for which im360_conv_gn_slabs
+ * returns S > 0 (slabs per image) can do it. */
+int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps);
 
 /* 1x1 convolution of the channel concatenation [xa | xb] without materialising it: the K loop reads channels [0, C1)
  * from xa and [C1, C1 + C2) from xb (C1, C2 multiples of 64); w_packed [CoutPad][1][C1 + C2]; + bias + res.
@@ -204,7 +218,7 @@ int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_pac
  * Replaces: nn.Linear (+ residual add) in front of nn.LayerNorm, animatediff/models/attention.py:264, 461-508;
  *   motion_module.py:172, 230-258; src/modules/transformer.py:156-165. */
 int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y, void* rowstats,
-                     int64_t M, int64_t K, int64_t N, int dtype, void* stream);
+                     int64_t M, int64_t K, int64_t N, int dtype, void* stream, void* gn_partial);
 
 /* Linear(LayerNorm(x)) with the normalisation folded into the GEMM: x [M, K] are the RAW rows, rowstats [M][rs_p][2] their
  * (sum, sum of squares) slices from im360_linear_fwd, w_packed = pack(gamma (.) W) and

@@ -132,7 +132,7 @@ def conv_up2(x, w4_packed, cout, bias=None, wrap=False):
 
 
 def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0, wout=None, temb=None,
-           imgs_per_temb=1, res=None, y_off=0):
+           imgs_per_temb=1, res=None, y_off=0, gn_stats=False):
     N, Hin, Win, Cin = x.shape
     taps = w_packed.shape[1]
     k = 3 if taps == 9 else 1
@@ -169,7 +169,7 @@ def conv1x1_cat(xa, xb, w_packed, cout, bias=None, res=None):
     return conv2d(torch.cat([xa, xb], dim=-1), w_packed, cout, bias=bias, res=res)
 
 
-def linear(x, w_packed, n, bias=None, res=None, row_stats=False):
+def linear(x, w_packed, n, bias=None, res=None, row_stats=False, gn_hw=None):
     """The statistics are those of the STORED (rounded) output, per 160-column slice, like the kernel's."""
     k = x.shape[-1]
     y = F.linear(x.float(), w_packed[:n, 0].float(), None if bias is None else bias.float())
@@ -261,6 +261,10 @@ def linear_geglu(x, w, b, inner):
 _NAMES = ["layer_norm", "geglu", "pack_geglu", "linear_geglu", "attention", "temporal_attention", "group_norm_stats", "group_norm_apply", "group_norm", "pack_conv_weight",
           "conv2d", "pack_conv_up2_weight", "conv_up2", "circular_pad_w", "circular_pad_hw", "cfg_ddim_update", "softmax_rows", "attention2", "pack_attn_bias",
           "conv1x1_cat", "linear", "linear_ln", "linear_geglu_ln", "interleave_geglu", "shard_pack"]
+
+
+def carry_gn(view, src):
+    return view
 
 
 @contextlib.contextmanager

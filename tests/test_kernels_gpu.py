@@ -914,3 +914,75 @@ def test_group_norm_single_launch_equals_the_three_kernel_path(dt, N, H, W, C1, 
             assert got.shape == (N, H, W + 2 * pad, C) and torch.equal(got, want)
     finally:
         K.GN_FUSED = False
+
+
+# ------------------------------------------------------------------ round 4: GroupNorm statistics from the producer's epilogue
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,taps", [(160, 32, 32, 320, 320, 9), (80, 32, 32, 320, 640, 9), (640, 16, 16, 640, 640, 1), (16, 64, 128, 320, 320, 9)])
+def test_group_norm_statistics_from_the_conv_epilogue(dt, N, H, W, Cin, Cout, taps):
+    """conv2d(..., gn_stats=True): the 256 x 320 tile's epilogue writes per tile and channel (sum, sum of squares) of the values it
+    stores (bias, time embedding and residual included); group_norm_stats() of the tagged tensor then runs only the finalize.
+    Against the statistics pass over the same tensor (fp32 summation order apart) and fp32 torch; and the tag dies with an
+    in-place write."""
+    g = torch.Generator().manual_seed(120)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dt).cuda()
+    w = (torch.randn(Cout, Cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) * (taps * Cin) ** -0.5).to(dt).cuda()
+    wp = K.pack_conv_weight(w)
+    b = (torch.randn(Cout, generator=g) * 0.3 + 0.5).to(dt).cuda()
+    temb = torch.randn(N // 8, Cout, generator=g).to(dt).cuda()
+    res = torch.randn(N, H, W, Cout, generator=g).to(dt).cuda()
+    y = K.conv2d(x, wp, Cout, bias=b, temb=temb, imgs_per_temb=8, res=res, gn_stats=True)
+    assert K._gn_of(y) is not None and K._gn_of(y)[1] == H * W // 256
+    assert torch.equal(y, K.conv2d(x, wp, Cout, bias=b, temb=temb, imgs_per_temb=8, res=res))        # same output bits as the plain epilogue
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).to(dt).cuda(), (0.1 * torch.randn(Cout, generator=g)).to(dt).cuda()
+    s1, h1 = K.group_norm_stats(y, gamma, beta, 32, 1e-5)
+    try:
+        K.GN_FROM_PRODUCER = False
+        s2, h2 = K.group_norm_stats(y, gamma, beta, 32, 1e-5)
+    finally:
+        K.GN_FROM_PRODUCER = True
+    assert rel(s1, s2) < 1e-5 and (h1 - h2).abs().max() < 1e-4 * (1 + float(h2.abs().max()))
+    ref = F.silu(F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, gamma.float().cpu(), beta.float().cpu(), 1e-5)).permute(0, 2, 3, 1)
+    assert rel(K.group_norm(y, gamma, beta, 32, 1e-5, silu=True), ref) < TOL[dt]
+    y.add_(1.0)                       # an in-place write invalidates the tag
+    assert K._gn_of(y) is None
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_group_norm_statistics_from_the_linear_epilogue_and_skip_pairs(dt):
+    """linear(..., gn_hw = pixels per image) on the persistent ring kernel (with and without the LayerNorm row statistics), and
+    the decoder's skip pairs: (tagged, untagged), (tagged, tagged) and mixed slab counts, each against the statistics pass."""
+    g = torch.Generator().manual_seed(121)
+    N, HW, C = 80, 1024, 320
+    x = torch.randn(N * HW, C, generator=g).to(dt).cuda()
+    wl = (torch.randn(C, C, generator=g) * C ** -0.5).to(dt).cuda()
+    wp = K.pack_conv_weight(wl.reshape(C, C, 1, 1))
+    b = torch.randn(C, generator=g).to(dt).cuda()
+    res = (torch.randn(N * HW, C, generator=g) + 0.7).to(dt).cuda()
+    y = K.linear(x, wp, C, bias=b, res=res, gn_hw=HW)
+    assert K._gn_of(y) is not None and torch.equal(y, K.linear(x, wp, C, bias=b, res=res))
+    y5, st = K.linear(x, wp, C, bias=b, res=res, row_stats=True, gn_hw=HW)
+    assert K._gn_of(y5) is not None and torch.equal(y5, y) and st is not None
+    gamma, beta = (1 + 0.1 * torch.randn(2 * C, generator=g)).to(dt).cuda(), (0.1 * torch.randn(2 * C, generator=g)).to(dt).cuda()
+    ya = K.carry_gn(y.reshape(N, 32, 32, C), y)
+    yb5 = K.carry_gn(y5.reshape(N, 32, 32, C), y5)
+    plain = (torch.randn(N, 32, 32, C, generator=g) * 2).to(dt).cuda()
+    assert K._gn_of(ya) is not None and K._gn_of(plain) is None
+
+    def both(xx, ga, be):
+        a = K.group_norm_stats(xx, ga, be, 32, 1e-5)
+        try:
+            K.GN_FROM_PRODUCER = False
+            r = K.group_norm_stats(xx, ga, be, 32, 1e-5)
+        finally:
+            K.GN_FROM_PRODUCER = True
+        assert rel(a[0], r[0]) < 1e-5 and (a[1] - r[1]).abs().max() < 1e-4 * (1 + float(r[1].abs().max())), (rel(a[0], r[0]), (a[1] - r[1]).abs().max())
+    both(ya, gamma[:C], beta[:C])
+    both((ya, plain), gamma, beta)          # 640 channels in 32 groups of 20: no group straddles the two sources
+    both((plain, yb5), gamma, beta)
+    both((ya, yb5), gamma, beta)
+    # groups that straddle the sources: 320 + 640 channels = 32 groups of 30
+    wide = torch.randn(N, 32, 32, 2 * C, generator=g).to(dt).cuda()
+    g3, b3 = (1 + 0.1 * torch.randn(3 * C, generator=g)).to(dt).cuda(), (0.1 * torch.randn(3 * C, generator=g)).to(dt).cuda()
+    both((ya, wide), g3, b3)
+    both((wide, ya), g3, b3)
