@@ -110,7 +110,9 @@ class Downsample3D(nn.Module):
         self.conv = InflatedConv3d(channels, self.out_channels, 3, stride=2, padding=padding)
 
     def forward_cl(self, x, pano=False):
-        return self.conv.forward_cl(x, wrap=pano)
+        # (the next ResnetBlock's norm1 reads this tensor: its GroupNorm partial sums come out of the epilogue; the panorama
+        #  branch normalises the PADDED tensor there -- edge columns weigh twice -- and takes its own statistics pass)
+        return self.conv.forward_cl(x, wrap=pano, gn_stats=not pano)
 
     def forward(self, hidden_states):
         x, f = to_cl(hidden_states)
