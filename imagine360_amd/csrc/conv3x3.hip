@@ -777,10 +777,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool GNS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
-    constexpr int BM = 256, BN = WN * TN * 32, BK = 32;
-    constexpr int CPR = BK / 8, ROWB = BK * 2, RPB = 256 / ROWB;      // 4 chunks per 64-byte row, 4 rows per bank row
+    constexpr bool STAG64 = (MODE & 15) == 3;
+    constexpr int ABL = MODE >> 4;                       // ablation builds of the loop (tools/ab_stag.py --ablate): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads                   // 64-channel stages in two buffers, staggered wave groups (below)
+    constexpr int BM = 256, BN = WN * TN * 32, BK = STAG64 ? 64 : 32;
+    constexpr int CPR = BK / 8, ROWB = BK * 2, RPB = 256 / ROWB;      // 4 chunks per 64-byte row, 4 rows per bank row (8 / 2 at 64 channels)
     constexpr int KC = BK / 16;
-    constexpr int NSLOT = 4;
+    constexpr int NSLOT = STAG64 ? 2 : 4;
     constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB, SLOT = TILE_A + TILE_B;
     constexpr int LDA = (BM * CPR) / NT;                  // 2 LDS-DMA loads per thread per phase: activations
     constexpr int LDB = (BN * CPR) / NT;                  // 2 full rounds of weights ...
@@ -788,7 +790,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     static_assert((BM * CPR) % NT == 0 && ((BN * CPR) % NT == 0 || (BN * CPR) % NT == NT / 2), "staging pattern");
     constexpr int EPI_ROWB = (EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
-    constexpr int RING_BYTES = NSLOT * SLOT > 2 * SLOT + EPI_BYTES ? NSLOT * SLOT : 2 * SLOT + EPI_BYTES;
+    constexpr int EPI_OFF = STAG64 ? SLOT : 2 * SLOT;          // the epilogue's staging starts behind the slots the next tile is prefetched into
+    constexpr int RING_BYTES = NSLOT * SLOT > EPI_OFF + EPI_BYTES ? NSLOT * SLOT : EPI_OFF + EPI_BYTES;
     constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
     constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (T-typed, BN entries)
     constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0));
@@ -943,7 +946,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     if (tile >= ntiles) return;
     init_tile(tile);
     issue(0);
-    if (nph > 1) issue(1);
+    if (!STAG64 && nph > 1) issue(1);
     for (;;) {
         const long m0 = tile_m0(tile);
         const int n0 = tile_n0(tile);
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 *(uint4*)((char*)cvec + tid * 16) = v;
             }
         }
-        if (nph > 2) issue(2);
+        if (!STAG64 && nph > 2) issue(2);
 
         f32x16 acc[TN][TM];
 #pragma unroll
@@ -1018,6 +1021,108 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                             acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+            }
+            if (!grp) asm volatile("s_barrier" ::: "memory");         // the leading group waits for the trailing one: aligned again
+        } else if constexpr (STAG64) {
+            // Round 4 (tools/dma_seg_probe.hip, profiles/r04_dma_seg_probe.txt): an LDS-DMA instruction that covers 64-byte
+            // row segments -- the 32-channel phases of the ring above -- gets 26 B/clk/CU out of the L2, one that covers whole
+            // 128-byte lines 52: the 36.9 KB of a 32-channel phase take longer to come out of the L2 (1400 clk) than its MFMAs
+            // take (1280), whatever the schedule.  Here a STAGE is 64 channels (whole lines), two stage buffers; its four
+            // 16-channel chunks run as two (R, C) interval pairs like MODE 1's: R fetches the 14 fragments of two chunks, C runs
+            // their 20 MFMAs from registers, a barrier after each, and the two wave groups (waves 0-3 / 4-7, one of each per
+            // SIMD) run one interval apart, so every SIMD has one wave in C while the other reads LDS.  In barrier intervals
+            // t (leading group: R(st,0) at 4 st, C(st,0) at 4 st + 1, R(st,1) at + 2, C(st,1) at + 3; trailing group one later):
+            //   * stage st + 1 goes into the buffer stage st - 1 was read from, last by the trailing group's R(st-1,1) at
+            //     4 st - 1: both groups request it during t = 4 st and 4 st + 1 (the leading one pieces 0-4 in R(st,0) and 5-8
+            //     between the MFMAs of C(st,0); the trailing one 0-4 between the MFMAs of C(st-1,1) and 5-8 in R(st,0)), so the
+            //     CU's request path sees half a stage per interval;
+            //   * every wave waits for its pieces (vmcnt(0): nothing younger is in flight) in front of the barrier that ends
+            //     t = 4 st + 3 (leading: end of C(st,1); trailing: end of R(st,1)); the first read is at t = 4 st + 4.
+            const int grp = wid_s >> 2;
+            constexpr int PA = (NPIECE + 1) / 2;           // pieces 0 .. PA-1 in the first of the two request intervals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage 0 (and the previous epilogue's stores)
+            asm volatile("s_barrier" ::: "memory");
+            if (grp) {
+                if (nph > 1 && !(ABL & 1)) static_for<PA>([&](auto ic) { issue_piece(1, ic); });
+                asm volatile("s_barrier" ::: "memory");          // the trailing group skips one interval
+            }
+            for (int st = 0; st < nph; ++st) {
+                const char* at = lds + (st & 1) * SLOT;
+                const bool req1 = st + 1 < nph && !(ABL & 1), req2 = st + 2 < nph && !(ABL & 1);
+                const int rs1 = (st + 1) & 1, rs2 = st & 1;
+                u32x4 xf[2][TM], wf[2][TN];
+                // ---- R(st, 0)
+                if (req1) {
+                    if (grp) {
+                        static_for<NPIECE - PA>([&](auto ic) { issue_piece(rs1, std::integral_constant<int, PA + decltype(ic)::value>{}); });
+                        issue_advance();
+                    } else {
+                        static_for<PA>([&](auto ic) { issue_piece(rs1, ic); });
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+if (ABL & 4) {
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) xf[kc][b] = u32x4{(uint32_t)st, 1u, 2u, 3u};
+#pragma unroll
+                        for (int a = 0; a < TN; ++a) wf[kc][a] = u32x4{(uint32_t)a, 1u, (uint32_t)st, 3u};
+                    }
+                } else
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(at + xrow + koff[kc] + b * (32 * ROWB));
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(at + wrow + koff[kc] + a * (32 * ROWB));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C(st, 0): the leading group's pieces PA .. NPIECE-1 of stage st + 1 between the MFMAs
+                __builtin_amdgcn_s_setprio(1);
+                static_for<2 * TN * TM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                    if (!(ABL & 2)) acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]); else { keep_alive(wf[kc][a]); keep_alive(xf[kc][b]); }
+                    if constexpr (m % 4 == 3 && m / 4 < NPIECE - PA) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (req1 && !grp) issue_piece(rs1, std::integral_constant<int, PA + m / 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                if (req1 && !grp) issue_advance();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                // ---- R(st, 1)
+if (!(ABL & 4))
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(at + xrow + koff[2 + kc] + b * (32 * ROWB));
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(at + wrow + koff[2 + kc] + a * (32 * ROWB));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing group: its pieces of stage st + 1
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- C(st, 1): the trailing group's pieces 0 .. PA-1 of stage st + 2 between the MFMAs
+                __builtin_amdgcn_s_setprio(1);
+                static_for<2 * TN * TM>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                    if (!(ABL & 2)) acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]); else { keep_alive(wf[kc][a]); keep_alive(xf[kc][b]); }
+                    if constexpr (m % 4 == 3 && m / 4 < PA) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (req2 && grp) issue_piece(rs2, std::integral_constant<int, m / 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // leading group: its pieces of stage st + 1
                 asm volatile("s_barrier" ::: "memory");
             }
             if (!grp) asm volatile("s_barrier" ::: "memory");         // the leading group waits for the trailing one: aligned again
@@ -1132,7 +1237,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         if (next < ntiles) {                             // keep the operand stream going under the epilogue
             init_tile(next);
             issue(0);
-            if (nph > 1) issue(1);
+            if (!STAG64 && nph > 1) issue(1);
         }
         // the epilogue's per-lane addressing (rows / pieces / swizzles of ten store rounds) is invariant across tiles: keep
         // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
@@ -1144,7 +1249,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN>(p, acc, lds + 2 * SLOT, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
         if (next >= ntiles) break;
         tile = next;
     }
@@ -1457,11 +1562,14 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
         }
         p.ngroups = grid >= 8u * ng ? ng : 1;
     }
-    // variant (knob conv_ring): 1 = asm LDS-DMA, pieces interleaved with the MFMAs (default); 2 = builtin LDS-DMA, plain ring;
-    // 3 = asm LDS-DMA, plain ring; 4 = asm LDS-DMA, staggered wave groups
+    // variant (knob conv_ring): 1 = default: token-major GEMMs on the staggered 64-channel-stage loop (MODE 3, round 4), convolutions
+    // sent here by knob value 5 on the interleaved ring (MODE 2); 8 = MODE 2 for the GEMMs too (round 2 / 3's default), 6 = MODE 3
+    // for everything; make ablate: 2 = builtin LDS-DMA, plain ring; 3 = asm LDS-DMA, plain ring; 4 = staggered wave groups on the ring
+    const bool stag = p.Cin % 64 == 0 && (variant == 6 || (LINEAR && variant != 8 && (variant < 2 || variant > 4)));
     if constexpr (LINEAR && TN == 5 && (EPI == 2 || EPI == 5)) {
         if (p.gn_out) {                         // GroupNorm partial sums from the epilogue (see ConvParams::gn_out)
-            hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2, true>), dim3(grid), dim3(512), 0, stream, p);
+            if (stag) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, true>), dim3(grid), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2, true>), dim3(grid), dim3(512), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }
@@ -1470,16 +1578,38 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
         im360_set_error("linear_fwd: GroupNorm statistics are produced by the plain / row-statistics epilogues only");
         return IM360_ERR_UNSUPPORTED;
     }
-    if constexpr (EPI >= 3) {                   // LayerNorm-folded / statistics-writing epilogues: the default pipeline only
-        hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
-    } else {
 #ifdef IM360_ABLATE
-    if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false, 0>), dim3(grid), dim3(512), 0, stream, p);
-    else if (variant == 3) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 0>), dim3(grid), dim3(512), 0, stream, p);
-    else if (variant == 4) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 1>), dim3(grid), dim3(512), 0, stream, p);
-    else
+    if constexpr (LINEAR && TN == 5 && EPI == 2) {
+        if (stag && p.dbg) {                    // ablation builds of the staggered loop (tools/ab_stag.py --ablate)
+            switch (p.dbg & 7) {
+#define IM360_ABL_CASE(a) case a: hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3 + 16 * a>), dim3(grid), dim3(512), 0, stream, p); break;
+                IM360_ABL_CASE(1) IM360_ABL_CASE(2) IM360_ABL_CASE(3) IM360_ABL_CASE(4) IM360_ABL_CASE(5) IM360_ABL_CASE(6) IM360_ABL_CASE(7)
+#undef IM360_ABL_CASE
+            }
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+    if constexpr (EPI < 3) {
+        if (variant == 2) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, false, 0>), dim3(grid), dim3(512), 0, stream, p);
+        else if (variant == 3) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 0>), dim3(grid), dim3(512), 0, stream, p);
+        else if (variant == 4) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 1>), dim3(grid), dim3(512), 0, stream, p);
+        if (variant >= 2 && variant <= 4) {
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
 #endif
-    hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+    if constexpr (LINEAR) {
+        if (stag) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+    } else {
+        // (3x3 convolutions on the staggered loop: 27 spilled registers, 0.90 - 1.13 PF/s against the two-stage kernel's 1.05 - 1.16: make ablate only)
+#ifdef IM360_ABLATE
+        if (stag) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3>), dim3(grid), dim3(512), 0, stream, p);
+        else
+#endif
+        hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     }
     IM360_CHECK_LAUNCH();
     return IM360_OK;
@@ -1539,8 +1669,8 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
         if (p.gn_out && !linear) return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
-        if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env);
-        if (ring_env >= 5) return launch_ring_t<T, 5, 0, false>(p, stream, 1);
+        if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env == 5 ? 1 : (ring_env == 7 ? 6 : ring_env));
+        if (ring_env >= 5) return launch_ring_t<T, 5, 0, false>(p, stream, ring_env == 7 ? 6 : 1);
         if (linear) return launch_conv_t<T, 4, 2, 2, 5, 2>(p, stream);
         return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
     }
@@ -1693,7 +1823,7 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
     }
 #endif
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
-        const int v = knob(KNOB_CONV_RING) >= 5 ? 1 : knob(KNOB_CONV_RING);
+        const int v = knob(KNOB_CONV_RING) == 5 ? 1 : (knob(KNOB_CONV_RING) == 7 ? 6 : knob(KNOB_CONV_RING));      // (5 / 7: the ring kernel for the convolutions too)
         if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);
         if (dtype == 1) return launch_ring_t<_Float16, 4, 1, true>(p, s, v);
     }
@@ -1750,8 +1880,9 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     p.gn_out = (float*)gn_partial;          // (per 256-row tile: the caller's images are whole numbers of tiles)
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
-    const int v = knob(KNOB_CONV_RING) >= 1 && knob(KNOB_CONV_RING) <= 4 ? knob(KNOB_CONV_RING) : 1;
-    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, 1);
+    const int kr = knob(KNOB_CONV_RING);
+    const int v = kr == 5 ? 1 : (kr == 7 ? 6 : kr);
+    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, v == 8 ? 8 : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, v == 8 ? 8 : 1);
     return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);
 }
 
@@ -1782,7 +1913,8 @@ extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const vo
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    return dtype == 0 ? launch_ring_t<__bf16, 5, 3, true>(p, (hipStream_t)stream, 1) : launch_ring_t<_Float16, 5, 3, true>(p, (hipStream_t)stream, 1);
+    const int v6 = knob(KNOB_CONV_RING) == 8 ? 8 : 1;
+    return dtype == 0 ? launch_ring_t<__bf16, 5, 3, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 5, 3, true>(p, (hipStream_t)stream, v6);
 }
 
 // LayerNorm folded into the fused GEGLU projection (im360_linear_geglu with w_packed = pack_geglu(gamma (.) W) and the
@@ -1806,7 +1938,8 @@ extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const 
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, 1) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, 1);
+    const int v6 = knob(KNOB_CONV_RING) == 8 ? 8 : 1;
+    return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);
 }
 
 extern "C" int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,

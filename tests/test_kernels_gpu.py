@@ -499,14 +499,14 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
     outs = {}
     try:
         K.tuning_set("conv_cm", 0)          # the ring kernel sums taps outermost: compare it with the tap-major two-stage kernel
-        for v in (0, 1, 3, 4, 5):
+        for v in (0, 1, 3, 4, 5, 8):
             K.tuning_set("conv_ring", v)
             outs[v] = (K.conv2d(x, wp, N, bias=b, res=r), K.linear_geglu(gx, gwp, gbp, 256),
                        K.conv2d(cx, cwp, 320, bias=b, temb=temb, imgs_per_temb=5, res=cres))
     finally:
         K.tuning_set("conv_ring", 1)
         K.tuning_set("conv_cm", 1)
-    for v in (1, 3, 4, 5):
+    for v in (1, 3, 4, 5, 8):
         for a, ref in zip(outs[v], outs[0]):
             assert torch.equal(a, ref), v
     lin_ref = (x[:, 0, 0].float() @ w[:, :, 0, 0].float().t() + b.float()).to(dt).float() + r[:, 0, 0].float()
@@ -514,6 +514,53 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
     conv_ref = (F.conv2d(cx.float().permute(0, 3, 1, 2), cw.float(), b.float(), padding=1).permute(0, 2, 3, 1)
                 + temb.float().repeat_interleave(5, 0)[:, None, None, :]).to(dt).float() + cres.float()
     assert rel(outs[5][2], conv_ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,Kd", [(131073, 320), (65536 + 77, 64), (70000, 1280)])
+def test_staggered_gemm_loop_every_epilogue_bit_identical_to_the_ring(dt, M, Kd):
+    """Round 4's default loop of the token-major GEMMs (64-channel stages in two buffers, two wave groups one barrier interval
+    apart: conv_ring 1) against round 3's (32-channel phases over a four-slot ring: conv_ring 8): same accumulation order, so
+    identical bits from every epilogue -- bias + residual, + LayerNorm row statistics, + GroupNorm partial sums, LayerNorm
+    folded in (with a positional table), GEGLU, GEGLU with LayerNorm folded in -- on ragged token counts with 1, 5 and 20 stages."""
+    g = torch.Generator().manual_seed(61)
+    N = 640
+    x = (torch.randn(M, Kd, generator=g) + 0.3).to(dt).cuda()
+    w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).to(dt).cuda()
+    b, r = torch.randn(N, generator=g).to(dt).cuda(), torch.randn(M, N, generator=g).to(dt).cuda()
+    wp = K.pack_conv_weight(w.reshape(N, Kd, 1, 1))
+    gam, bet = (1 + 0.1 * torch.randn(Kd, generator=g)).to(dt).cuda(), (0.1 * torch.randn(Kd, generator=g)).to(dt).cuda()
+    wg, c1, c2 = K.fold_layer_norm(w, b, gam, bet)
+    wgp = K.pack_conv_weight(wg.reshape(N, Kd, 1, 1).contiguous())
+    tab = torch.randn(3, N, generator=g).cuda()
+    gw, gb = (torch.randn(1024, Kd, generator=g) * Kd ** -0.5).to(dt).cuda(), torch.randn(1024, generator=g).to(dt).cuda()
+    gwp, gbp = K.pack_geglu(gw, gb)
+    gwf, gc1, gc2 = K.fold_layer_norm(gw, gb, gam, bet)
+    gwfp, gc1p = K.pack_geglu(gwf, gc1)
+    gc2p = K.interleave_geglu(gwf, gc2)[1].contiguous()
+    # row statistics of x itself, in the producer's layout (per 160-column slice; the consumer sums the slices)
+    sl = K.ROW_SLICE
+    if Kd % sl == 0:
+        xs = x.float().reshape(M, Kd // sl, sl)
+        st = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()
+    else:
+        st = torch.stack([x.float().sum(-1, keepdim=True), (x.float() ** 2).sum(-1, keepdim=True)], dim=-1).contiguous()
+    m256 = (M // 256) * 256
+    outs = {}
+    try:
+        for v in (1, 8):
+            K.tuning_set("conv_ring", v)
+            y5, s5 = K.linear(x, wp, N, bias=b, res=r, row_stats=True)
+            yg = K.linear(x[:m256], wp, N, bias=b, res=r[:m256], gn_hw=256)
+            outs[v] = (K.linear(x, wp, N, bias=b, res=r), y5, s5, yg, K._gn_of(yg)[0] if K._gn_of(yg) is not None else yg,
+                       K.linear_ln(x, wgp, c1, c2, st, 1e-5, N, tab=tab, tab_div=256),
+                       K.linear_geglu(x, gwp, gbp, 512), K.linear_geglu_ln(x, gwfp, gc1p.contiguous(), gc2p, st, 1e-5, 512))
+    finally:
+        K.tuning_set("conv_ring", 1)
+    for i, (a, ref) in enumerate(zip(outs[1], outs[8])):
+        assert torch.equal(a, ref), i
+    ref = (x.float() @ w.float().t() + b.float()).to(dt).float() + r.float()
+    assert rel(outs[1][0], ref) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTYPES)
