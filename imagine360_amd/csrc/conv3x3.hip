@@ -512,7 +512,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // UP2 (4 taps): one output parity of nearest-x2-upsample + conv3x3 as a 2 x 2 convolution of the low-resolution input with
 // pre-summed weights (after the upsample every output parity sees only 2 x 2 distinct source pixels): tap (r, c) reads
 // source pixel (y + r + py - 1, x + c + px - 1); 4 / 9 of the MACs of the upsampled form.
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false, bool GNS = false>
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false, bool GNS = false, bool STAG = false>
 // (waves per SIMD given as min AND max: with the minimum alone hipcc aimed the 256 x 64 tile at three waves per SIMD -- 168 registers --
 //  and spilled 688 bytes inside the K loop once ConvParams grew in round 3: 1.58 ms instead of 0.25 ms for a cfg1-sized 320 -> 320
 //  convolution; its LDS footprint allows two workgroups per CU anyway)
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     }
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
 
+    const uint32_t lds_u32 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
     // one LDS-DMA piece (1 KiB per wave) of the next K step: pieces 0 .. LDA-1 are the pixel rows, LDA .. LDA+LDB-1 the weights;
     // the producer state only moves in stage_advance(), so the pieces of a step can be issued anywhere inside the step
     auto stage_piece = [&](int buf, auto jc) {
@@ -646,12 +647,16 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
             const T* src;
             if constexpr (CM) src = ((vmask[j] >> tap_p) & 1u) ? aptr[j] + (tapdelta + kofs) : zero;
             else src = aptr[j];
+            if constexpr (STAG) lds_dma16_asm(src, lds_u32 + (uint32_t)(buf * STAGE + wid_s * 1024 + j * (NT * 16)));
+            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(abase + j * (NT * 16)), 16, 0, 0);
         } else {
             constexpr int i = j - LDA;
             const T* src = bptr + i * bstride;
             if constexpr (CM) src += (long)tap_p * p.Cin + kofs;
+            if constexpr (STAG) lds_dma16_asm(src, lds_u32 + (uint32_t)(buf * STAGE + wid_s * 1024 + TILE_A + i * (NT * 16)));
+            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(bbase + i * (NT * 16)), 16, 0, 0);
         }
@@ -697,6 +702,89 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     const int wrow = (wn * (TN * 32) + col) * ROWB, xrow = (wm * (TM * 32) + col) * ROWB;
 
     stage(0);
+    if constexpr (STAG) {
+        // The staggered loop of conv_ring_kernel's MODE 3 (see there for the interval arithmetic) on this kernel's producer: each
+        // 64-channel step as two (R, C) interval pairs -- R fetches the 14 fragments of two 16-channel chunks, C runs their 20 MFMAs
+        // from registers --, the wave groups 0-3 / 4-7 one barrier interval apart so that every SIMD has one wave in C while its
+        // other wave reads LDS; step s + 1 is requested during the two intervals after the last read of step s - 1 and waited for
+        // (vmcnt(0): nothing younger in flight) in front of the barrier that ends step s.
+        static_assert(!STAG || (NT == 512 && BK == 64), "staggered loop: the 8-wave tile on 64-channel steps");
+        constexpr int NP = LDA + LDB, PA = (NP + 1) / 2;
+        const int grp = wid_s >> 2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (grp) {
+            if (nsteps > 1) static_for<PA>([&](auto ic) { stage_piece(1, ic); });
+            asm volatile("s_barrier" ::: "memory");
+        }
+        const char* bt0 = lds + TILE_A;
+        for (int s = 0; s < nsteps; ++s) {
+            const char* at = lds + (s & 1) * STAGE;
+            const char* bt = bt0 + (s & 1) * STAGE;
+            const bool req1 = s + 1 < nsteps, req2 = s + 2 < nsteps;
+            const int rs1 = (s + 1) & 1, rs2 = s & 1;
+            u32x4 xf[2][TM], wf[2][TN];
+            if (req1) {
+                if (grp) {
+                    static_for<NP - PA>([&](auto ic) { stage_piece(rs1, std::integral_constant<int, PA + decltype(ic)::value>{}); });
+                    stage_advance();
+                } else {
+                    static_for<PA>([&](auto ic) { stage_piece(rs1, ic); });
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(at + xrow + koff[kc] + b * (32 * ROWB));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(bt + wrow + koff[kc] + a * (32 * ROWB));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            static_for<2 * TN * TM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                if constexpr (m % 4 == 3 && m / 4 < NP - PA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (req1 && !grp) stage_piece(rs1, std::integral_constant<int, PA + m / 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if (req1 && !grp) stage_advance();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(at + xrow + koff[2 + kc] + b * (32 * ROWB));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(bt + wrow + koff[2 + kc] + a * (32 * ROWB));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            static_for<2 * TN * TM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                if constexpr (m % 4 == 3 && m / 4 < PA) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (req2 && grp) stage_piece(rs2, std::integral_constant<int, m / 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+        if (!grp) asm volatile("s_barrier" ::: "memory");
+    } else
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();              // step s landed (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free again
         const bool more = s + 1 < nsteps && !(ABL && (p.dbg & 1));
@@ -1511,6 +1599,22 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     }
 #endif
     if constexpr (WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0) {
+#ifdef IM360_ABLATE
+        // staggered wave groups on this kernel's producer (round 4; knob conv_stag): identical bits, 0.97 - 1.05 x the plain loop's
+        // speed on the nine cfg2 convolution shapes (profiles/r04_conv_stag_ab.log) -- with two stage buffers a step's operands have
+        // one step to arrive either way, and that latency, not the fragment reads the stagger hides, is what the loop waits for
+        if (knob(KNOB_CONV_STAG) && p.Cin % 64 == 0 && bk_env != 32) {
+            if (p.gn_out) {
+                if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            } else {
+                if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            }
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+#endif
         if (p.gn_out) {            // the 256 x 320 tile with GroupNorm statistics from its epilogue
             if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
             else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);

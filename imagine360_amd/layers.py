@@ -6,6 +6,8 @@ classes take/return the reference layout ``[b, c, f, h, w]``; ``forward_cl`` met
 internal path.  All arithmetic-heavy work goes through ``imagine360_amd.kernels`` (HIP); GEMM-shaped
 Linear layers use torch (hipBLASLt), as SURVEY.md section 2b allows.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -123,7 +125,8 @@ def layer_norm(norm, x, pre=None, post=None, post_div=1):
     return kernels.layer_norm(x.contiguous(), norm.weight, norm.bias, norm.eps, pre=pre, post=post, post_div=post_div)
 
 
-ROUTE_MIN_TOKENS = 65536      # token-major GEMMs with at least this many rows go to the MFMA ring kernel (tests lower it)
+ROUTE_MIN_TOKENS = int(os.environ.get("IM360_ROUTE_MIN_TOKENS", 65536))      # token-major GEMMs with at least this many rows go to the MFMA ring kernel (tests lower it; the variable is for A/B runs of bench.py)
+GEGLU_FUSED_MAX_K = int(os.environ.get("IM360_GEGLU_MAX_K", 640))       # widest input the fused GEGLU projection takes (see GEGLU.forward)
 ROUTE_ON_CPU = False          # tests only: take the routed branch without a GPU (kernels monkeypatched by torch stand-ins)
 ROUTE_N_MULT = 320            # output widths the ring kernel's 320-column tiles cover (tests on stand-ins lower it)
 
@@ -213,7 +216,7 @@ class GEGLU(nn.Module):
         # large token counts: projection, bias and the gated activation in ONE launch of the MFMA GEMM kernel (the
         # 2I-wide intermediate never goes to HBM); otherwise hipBLASLt + the elementwise kernel
         # (measured, tools/bench_kernels.py geglu_fused: wins for K <= 640 at >= 64k tokens, loses at K = 1280 / 40k)
-        fused = (x.is_cuda or ROUTE_ON_CPU) and k % 64 == 0 and k <= 640 and two_i % 256 == 0 and m >= ROUTE_MIN_TOKENS
+        fused = (x.is_cuda or ROUTE_ON_CPU) and k % 64 == 0 and k <= GEGLU_FUSED_MAX_K and two_i % 256 == 0 and m >= ROUTE_MIN_TOKENS
         cache = _module_cache(self)
         bias = None if self.proj.bias is None else self.proj.bias.detach()
         if fused and ln is not None and stats is not None:

@@ -47,22 +47,25 @@ for name, M, C in ([] if ("--only-ablate" in sys.argv or "--only" in sys.argv) e
     ab("geglu " + name, lambda: K.linear_geglu(x, wp, bp, 4 * C), 2.0 * M * C * 8 * C)
     del x, w, b, wp, bp
 if "--conv" in sys.argv:
-    for name, N, H, W, Cin, Cout in [("pers L0 320->320", 640, 32, 32, 320, 320), ("pers L0 640->320", 640, 32, 32, 640, 320),
-                                     ("pers L1 640->640", 640, 16, 16, 640, 640), ("pano L0 320->320", 32, 64, 128, 320, 320)]:
+    for name, N, H, W, Cin, Cout, kw in [("pers L0 320->320", 640, 32, 32, 320, 320, {}), ("pers L0 640->320", 640, 32, 32, 640, 320, {}),
+                                         ("pers L0 960->320", 640, 32, 32, 960, 320, {}), ("pers L1 640->640", 640, 16, 16, 640, 640, {}),
+                                         ("pers L1 1920->640", 640, 16, 16, 1920, 640, {}), ("pano L0 320->320 (W+4)", 32, 64, 132, 320, 320, dict(x_off=2, wout=128)),
+                                         ("pano L0 wrap", 32, 64, 128, 320, 320, dict(wrap=True)), ("pers L0 stride 2", 640, 32, 32, 320, 320, dict(stride=2)),
+                                         ("pers L0 320->320 gn", 640, 32, 32, 320, 320, dict(gn_stats=True))]:
         x, w, b = rn(N, H, W, Cin), rn(Cout, Cin, 3, 3) * (9 * Cin) ** -0.5, rn(Cout)
         wp = K.pack_conv_weight(w)
-        fl = 2.0 * N * H * W * Cin * Cout * 9
-        K.tuning_set("conv_ring", 1)
-        t0 = timeit(lambda: K.conv2d(x, wp, Cout, bias=b), iters)
-        y0 = K.conv2d(x, wp, Cout, bias=b).clone()
-        rowtxt = [f"two-stage: {t0 * 1e3:7.3f} ms {fl / t0 / 1e12:6.0f} TF/s"]
-        for v in (5, 7):
-            K.tuning_set("conv_ring", v)
-            y = K.conv2d(x, wp, Cout, bias=b).clone()
-            t = timeit(lambda: K.conv2d(x, wp, Cout, bias=b), iters)
-            rowtxt.append(f"ring v{v}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.0f} TF/s same {torch.equal(y, y0)} maxdiff {(y.float() - y0.float()).abs().max().item():.3g}")
-        K.tuning_set("conv_ring", 1)
-        print(f"conv {name:20s} " + " | ".join(rowtxt), flush=True)
+        fl = 2.0 * N * H * W * Cin * Cout * 9 / (kw.get("stride", 1) ** 2)
+        rowtxt, ys = [], []
+        for v in (0, 1):
+            K.tuning_set("conv_stag", v)
+            y = K.conv2d(x, wp, Cout, bias=b, **kw)
+            g = K._gn_of(y)
+            ys.append((y.clone(), None if g is None else g[0].clone()))
+            t = timeit(lambda: K.conv2d(x, wp, Cout, bias=b, **kw), iters)
+            rowtxt.append(f"stag {v}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.0f} TF/s")
+        K.tuning_set("conv_stag", 0)
+        same = torch.equal(ys[0][0], ys[1][0]) and (ys[0][1] is None or torch.equal(ys[0][1], ys[1][1]))
+        print(f"conv {name:24s} " + " | ".join(rowtxt) + f" | identical {same}", flush=True)
 if "--ablate" in sys.argv:
     # ablation builds of the staggered loop (make ablate): conv_dbg bits 1 = no LDS-DMA, 2 = no MFMA, 4 = no fragment reads
     assert K.ablate_build(), "needs `make -C imagine360_amd/csrc ablate`"
