@@ -81,7 +81,38 @@ __device__ __forceinline__ void keep_alive(f32x16 v) { asm volatile("" ::"v"(v))
 // UP2: the tile's rows are pixels of the LOW-resolution grid [N, Hout, Wout]; row (n, y, x) is stored at pixel
 // (n, 2 y + up2_py, 2 x + up2_px) of the [N, 2 Hout, 2 Wout, Cout] output (sub-pixel form of nearest-x2 + conv3x3).
 // cvec (EPI 3 / 4): the tile's fp32 column vectors staged in LDS by the caller, [0, BN) = c1, [BN, 2 BN) = c2 (+ table row).
-template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2>
+// (row, 16-byte piece) of `lane` in store round `it` of a 32-row block whose rows hold PIECES pieces; false: the lane idles in this
+// round (GNS only: every lane keeps ONE piece through all rounds, RPR = 64 / PIECES whole rows per round)
+template <int PIECES, bool GNS>
+__device__ __forceinline__ bool epi_round_rc(int it, int lane, int& row, int& pc) {
+    if constexpr (GNS) {
+        constexpr int RPR = 64 / PIECES;
+        row = it * RPR + lane / PIECES;
+        pc = lane % PIECES;
+        const bool act = lane < RPR * PIECES && row < 32;
+        row = row < 32 ? row : 31;
+        return act;
+    } else {
+        const int f = it * 64 + lane;
+        row = f / PIECES;
+        pc = f % PIECES;
+        return true;
+    }
+}
+template <int PIECES, bool GNS>
+constexpr int epi_rounds() { return GNS ? (32 + 64 / PIECES - 1) / (64 / PIECES) : (32 * PIECES) / 64; }
+// RESM: 0 = residual known at run time only (its loads are unconditional: an absent one reads the zero chunk); 1 = residual
+// present; 2 = no residual: the row-major pass moves whole 16-byte pieces LDS -> memory without unpacking them.  Round 4
+// (tools/patches/ring_cycle_stamps.patch: cycle stamps of one workgroup): the plain epilogue of a 256 x 320 tile takes 14 000
+// cycles and is VECTOR-bound (~ 6 instructions per element, more than half of them the unpack / add / repack of the row-major
+// pass), 28 000 with a residual whose two loads per block each expose an HBM latency.  RESM 2 drops the row-major pass's
+// arithmetic; requesting the residual pieces of BOTH blocks ahead (RESM 1's first form) put 90 - 110 registers into scratch next
+// to the 160 accumulators; requesting block 0's from the kernel right behind its last MFMA (no scratch once the lane id was kept from
+// being hoisted: a scratch reload is a VMEM load whose wait also waits for the pieces in front of it) measured 0.318 vs 0.306 ms on the
+// level-0 out-projection + residual -- that GEMM moves 1.26 GB in 0.31 ms, it is at the HBM rate, not waiting for a latency.  Both
+// dropped: RESM 1 requests per block, half before and half behind its register -> LDS pass.
+// Same arithmetic in all three: identical values (RESM 2 keeps the sign of a zero that x + 0 would clear).
+template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2, int RESM = 0>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
                                               int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0) {
     const int col = lane & 31, hi = lane >> 5;
@@ -260,11 +291,22 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 ln_rstds[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - ln_mus[b] * ln_mus[b], 0.f) + p.ln_eps);
             }
         }
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
+        constexpr int NIT = epi_rounds<PIECES, GNS>(), NIT1 = NIT / 2;
+        u32x4 rvs[1][NIT];
+        auto round_rc = [&](int it, int& row, int& pc) { return epi_round_rc<PIECES, GNS>(it, lane, row, pc); };
+        auto piece_off_r = [&](int it, int rows, bool& ok) {      // element offset of this lane's piece in round `it` (clamped into the block)
+            int row, pc;
+            const bool act = round_rc(it, row, pc);
+            const int co = nw0 + pc * 8;
+            ok = act && row < rows && co < p.Cout;
+            return (uint32_t)((row < rows ? row : rows - 1) * p.Cout + (co < cmax8 ? co : cmax8));
+        };
+        static_for<TM>([&](auto bcc) {
+            constexpr int b = decltype(bcc)::value;
             const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block (wave-uniform)
-            if (mb >= p.M) continue;
+            if (mb >= p.M) return;
             const int rows = p.M - mb < 32 ? (int)(p.M - mb) : 32;  // valid rows of the block
+            u32x4 (&rv)[NIT] = rvs[0];
             const char* rbase = res ? (const char*)(res + mb * p.Cout) : zsrc;
             char* ybase = (char*)(yg + mb * p.Cout);
             const long m = mb + (col < rows ? col : rows - 1);
@@ -276,35 +318,14 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             // residual pieces of this block: the first half is requested before the register -> LDS pass, the second
             // right after it (the accumulators it frees make room), so the HBM latency overlaps the shuffle work
-            constexpr int NIT = GNS ? (32 + RPR - 1) / RPR : (32 * PIECES) / 64, NIT1 = NIT / 2;
-            u32x4 rv[NIT];
-            // (row, piece) of this lane in store round `it`; false: the lane idles in this round (GNS only)
-            auto round_rc = [&](int it, int& row, int& pc) {
-                if constexpr (GNS) {
-                    row = it * RPR + lane / PIECES;
-                    pc = lane % PIECES;
-                    const bool act = lane < RPR * PIECES && row < 32;
-                    row = row < 32 ? row : 31;
-                    return act;
-                } else {
-                    const int f = it * 64 + lane;
-                    row = f / PIECES;
-                    pc = f % PIECES;
-                    return true;
-                }
-            };
-            auto piece_off = [&](int it, bool& ok) {      // element offset of this lane's piece in round `it` (clamped into the block)
-                int row, pc;
-                const bool act = round_rc(it, row, pc);
-                const int co = nw0 + pc * 8;
-                ok = act && row < rows && co < p.Cout;
-                return (uint32_t)((row < rows ? row : rows - 1) * p.Cout + (co < cmax8 ? co : cmax8));
-            };
+            auto piece_off = [&](int it, bool& ok) { return piece_off_r(it, rows, ok); };
             auto load_res = [&](int it0, int it1) {
+                if constexpr (RESM != 2) {
 #pragma unroll
-                for (int it = it0; it < it1; ++it) {
-                    bool ok;
-                    rv[it] = *(const u32x4*)(rbase + piece_off(it, ok) * rmul);
+                    for (int it = it0; it < it1; ++it) {
+                        bool ok;
+                        rv[it] = *(const u32x4*)(rbase + piece_off(it, ok) * (RESM == 1 ? 2u : rmul));
+                    }
                 }
             };
             load_res(0, NIT1);
@@ -328,13 +349,17 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 } else {
                 uint2 wb[4], wt[4];
+                f32x4 wbf[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = nw0 + a * 32 + 8 * g + 4 * hi;
                     const uint32_t cc = (uint32_t)(co < cmax4 ? co : cmax4);
                     if constexpr (EPI == 2 || EPI == 5) {
                         // (the persistent kernel staged the tile's bias slice in LDS; other callers pass no cvec)
-                        wb[g] = cvec ? *(const uint2*)((const char*)cvec + (co - n0) * 2) : *(const uint2*)(bsrc + cc * bmul);
+                        // (COUT8 = the persistent kernel: it staged the tile's bias slice in LDS -- a compile-time fact, a run-time test of the
+                        //  pointer costs a scalar branch per load, 40 per block)
+                        if constexpr (COUT8) wbf[g] = *(const f32x4*)(cvec + (co - n0));      // fp32 since round 4: no unpack in this pass
+                        else wb[g] = *(const uint2*)(bsrc + cc * bmul);
                     } else {
                         wb[g] = *(const uint2*)(bsrc + cc * bmul);
                     }
@@ -345,7 +370,12 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     float f[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
-                    f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
+                    if constexpr (COUT8 && (EPI == 2 || EPI == 5)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) f[j] += wbf[g][j];
+                    } else {
+                        f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
+                    }
                     if constexpr (EPI == 0) {
                         f[0] += unpack_lo<T>(wt[g].x); f[1] += unpack_hi<T>(wt[g].x); f[2] += unpack_lo<T>(wt[g].y); f[3] += unpack_hi<T>(wt[g].y);
                     }
@@ -367,6 +397,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 const bool act = round_rc(it, row, pc);
                 uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
                 if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
+                if constexpr (RESM != 2) {
                 const u32x4 w = rv[it];
                 float fv[8] = {unpack_lo<T>(o.x) + unpack_lo<T>(w.x), unpack_hi<T>(o.x) + unpack_hi<T>(w.x), unpack_lo<T>(o.y) + unpack_lo<T>(w.y), unpack_hi<T>(o.y) + unpack_hi<T>(w.y),
                                unpack_lo<T>(o.z) + unpack_lo<T>(w.z), unpack_hi<T>(o.z) + unpack_hi<T>(w.z), unpack_lo<T>(o.w) + unpack_lo<T>(w.w), unpack_hi<T>(o.w) + unpack_hi<T>(w.w)};
@@ -374,6 +405,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 o.y = pack2<T>(fv[2], fv[3]);
                 o.z = pack2<T>(fv[4], fv[5]);
                 o.w = pack2<T>(fv[6], fv[7]);
+                }
                 bool ok;
                 const uint32_t off = piece_off(it, ok);
                 if constexpr (GNS) {
@@ -430,7 +462,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();      // the next block overwrites the staging rows
-        }
+        });
         if constexpr (GNS) {
             // this wave's staging rows are free: park the lane's 16 sums there ([lane][16] floats), then -- after a workgroup
             // barrier -- thread c of the tile adds up channel c over the waves that stored its rows (same wn, every wm) and
@@ -512,7 +544,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
 // UP2 (4 taps): one output parity of nearest-x2-upsample + conv3x3 as a 2 x 2 convolution of the low-resolution input with
 // pre-summed weights (after the upsample every output parity sees only 2 x 2 distinct source pixels): tap (r, c) reads
 // source pixel (y + r + py - 1, x + c + px - 1); 4 / 9 of the MACs of the upsampled form.
-template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false, bool GNS = false, bool STAG = false>
+template <typename T, int BK, int WM, int WN, int TM, int TN, int EPI = 0, bool CM = false, bool ABL = false, bool UP2 = false, bool GNS = false, bool STAG = false, int RESM = 0>
 // (waves per SIMD given as min AND max: with the minimum alone hipcc aimed the 256 x 64 tile at three waves per SIMD -- 168 registers --
 //  and spilled 688 bytes inside the K loop once ConvParams grew in round 3: 1.58 ms instead of 0.25 ms for a cfg1-sized 320 -> 320
 //  convolution; its LDS footprint allows two workgroups per CU anyway)
@@ -847,7 +879,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     static_assert((NT / 64) * 32 * ((EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
-    tile_epilogue<T, NT, TM, TN, EPI, false, UP2, GNS, WN>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
+    tile_epilogue<T, NT, TM, TN, EPI, false, UP2, GNS, WN, RESM>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
 
 // ---- persistent, ring-pipelined variant of the 8-wave tile (256 pixels x 64 TN couts) ------------------------------
@@ -862,7 +894,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 //     slots 2 / 3), so the operand stream keeps flowing while accumulators are converted and stored.
 // Accumulation order over K is the same as in the kernel above (16 channels per MFMA, ascending), so results are
 // bit-identical.
-template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool GNS = false>
+template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool GNS = false, int RESM = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
     constexpr bool STAG64 = (MODE & 15) == 3;
@@ -881,8 +913,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int EPI_OFF = STAG64 ? SLOT : 2 * SLOT;          // the epilogue's staging starts behind the slots the next tile is prefetched into
     constexpr int RING_BYTES = NSLOT * SLOT > EPI_OFF + EPI_BYTES ? NSLOT * SLOT : EPI_OFF + EPI_BYTES;
     constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
-    constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (T-typed, BN entries)
-    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0));
+    constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (fp32, BN entries)
+    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 4 : 0));
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     float* cvec = (float*)(lds + RING_BYTES);
@@ -1055,7 +1087,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
             // load (an L2 round trip the ten-phase K loop of these GEMMs cannot hide)
             if (tid < BN / 8) {
                 const uint4 v = p.bias ? *(const uint4*)((const T*)p.bias + n0 + tid * 8) : uint4{0u, 0u, 0u, 0u};
-                *(uint4*)((char*)cvec + tid * 16) = v;
+                *(f32x4*)(cvec + tid * 8) = f32x4{unpack_lo<T>(v.x), unpack_hi<T>(v.x), unpack_lo<T>(v.y), unpack_hi<T>(v.y)};
+                *(f32x4*)(cvec + tid * 8 + 4) = f32x4{unpack_lo<T>(v.z), unpack_hi<T>(v.z), unpack_lo<T>(v.w), unpack_hi<T>(v.w)};
             }
         }
         if (!STAG64 && nph > 2) issue(2);
@@ -1337,7 +1370,7 @@ if (!(ABL & 4))
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
         if (next >= ntiles) break;
         tile = next;
     }
@@ -1615,9 +1648,17 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
             return IM360_OK;
         }
 #endif
-        if (p.gn_out) {            // the 256 x 320 tile with GroupNorm statistics from its epilogue
-            if (cm) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+        if (p.gn_out) {            // the 256 x 320 tile with GroupNorm statistics from its epilogue (per residual mode of the epilogue)
+            if (cm) {
+                if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 1>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 2>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            } else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+        if (cm) {
+            if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 1>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 2>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }
@@ -1670,9 +1711,21 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     // sent here by knob value 5 on the interleaved ring (MODE 2); 8 = MODE 2 for the GEMMs too (round 2 / 3's default), 6 = MODE 3
     // for everything; make ablate: 2 = builtin LDS-DMA, plain ring; 3 = asm LDS-DMA, plain ring; 4 = staggered wave groups on the ring
     const bool stag = p.Cin % 64 == 0 && (variant == 6 || (LINEAR && variant != 8 && (variant < 2 || variant > 4)));
+    // the default loop's kernels exist per residual mode of the epilogue (tile_epilogue, RESM): present / absent are different code
+    auto launch_stag = [&](auto gns_c) {
+        constexpr bool G = decltype(gns_c)::value;
+        if constexpr (EPI == 1 || EPI == 4) {
+            hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 0>), dim3(grid), dim3(512), 0, stream, p);
+        } else if constexpr (EPI == 3) {
+            hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 2>), dim3(grid), dim3(512), 0, stream, p);
+        } else {
+            if (p.res) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 1>), dim3(grid), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 2>), dim3(grid), dim3(512), 0, stream, p);
+        }
+    };
     if constexpr (LINEAR && TN == 5 && (EPI == 2 || EPI == 5)) {
         if (p.gn_out) {                         // GroupNorm partial sums from the epilogue (see ConvParams::gn_out)
-            if (stag) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, true>), dim3(grid), dim3(512), 0, stream, p);
+            if (stag) launch_stag(std::true_type{});
             else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2, true>), dim3(grid), dim3(512), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
@@ -1705,7 +1758,7 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     }
 #endif
     if constexpr (LINEAR) {
-        if (stag) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3>), dim3(grid), dim3(512), 0, stream, p);
+        if (stag) launch_stag(std::false_type{});
         else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 2>), dim3(grid), dim3(512), 0, stream, p);
     } else {
         // (3x3 convolutions on the staggered loop: 27 spilled registers, 0.90 - 1.13 PF/s against the two-stage kernel's 1.05 - 1.16: make ablate only)
