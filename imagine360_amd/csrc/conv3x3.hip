@@ -349,7 +349,6 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                 } else {
                 uint2 wb[4], wt[4];
-                f32x4 wbf[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = nw0 + a * 32 + 8 * g + 4 * hi;
@@ -358,7 +357,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                         // (the persistent kernel staged the tile's bias slice in LDS; other callers pass no cvec)
                         // (COUT8 = the persistent kernel: it staged the tile's bias slice in LDS -- a compile-time fact, a run-time test of the
                         //  pointer costs a scalar branch per load, 40 per block)
-                        if constexpr (COUT8) wbf[g] = *(const f32x4*)(cvec + (co - n0));      // fp32 since round 4: no unpack in this pass
+                        if constexpr (COUT8) wb[g] = *(const uint2*)((const char*)cvec + (co - n0) * 2);
                         else wb[g] = *(const uint2*)(bsrc + cc * bmul);
                     } else {
                         wb[g] = *(const uint2*)(bsrc + cc * bmul);
@@ -370,12 +369,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     float f[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
-                    if constexpr (COUT8 && (EPI == 2 || EPI == 5)) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) f[j] += wbf[g][j];
-                    } else {
-                        f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
-                    }
+                    f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
                     if constexpr (EPI == 0) {
                         f[0] += unpack_lo<T>(wt[g].x); f[1] += unpack_hi<T>(wt[g].x); f[2] += unpack_lo<T>(wt[g].y); f[3] += unpack_hi<T>(wt[g].y);
                     }
@@ -913,12 +907,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int EPI_OFF = STAG64 ? SLOT : 2 * SLOT;          // the epilogue's staging starts behind the slots the next tile is prefetched into
     constexpr int RING_BYTES = NSLOT * SLOT > EPI_OFF + EPI_BYTES ? NSLOT * SLOT : EPI_OFF + EPI_BYTES;
     constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
-    constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (fp32, BN entries)
-    constexpr int LDS_BYTES = RING_BYTES + (LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 4 : 0));
+    constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (T-typed, BN entries)
+    constexpr int CVB = LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0);       // bytes of one tile's column vectors
+    // (staggered loop: TWO sets -- the next tile's are loaded before and written behind this tile's epilogue, see the tile boundary)
+    constexpr int LDS_BYTES = RING_BYTES + (STAG64 ? 2 : 1) * CVB;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    float* cvec = (float*)(lds + RING_BYTES);
-
+    float* const cvec0 = (float*)(lds + RING_BYTES);
+    float* cvec = cvec0;
+    int cpar = 0;                 // (staggered loop) which set of column vectors this tile reads
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int col = lane & 31, hi = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
@@ -1062,33 +1059,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int kc = 0; kc < KC; ++kc) koff[kc] = ((kc * 2 + hi) ^ swz) * 16;
     const int wrow = (wn * (TN * 32) + col) * ROWB + TILE_A, xrow = (wm * (TM * 32) + col) * ROWB;
 
+    // (staggered loop) the column vectors of the tile at (m0n, n0n) -> set `set`, by LDS-DMA: no register carries them across the
+    // epilogue and hipcc's wait bookkeeping never sees the load (a visible one made it put vmcnt(0) in front of every fragment read
+    // of the K loop).  Thread t supplies bytes [16 t, 16 t + 16) of the set: LNF c1 | c2 (fp32; with a table, its row for this tile,
+    // which includes c2: host-folded), BIAS_LDS the T-typed bias slice (zeros without a bias).
+    auto cv_fill = [&](long m0n, int n0n, int set) {
+        constexpr int NL = LNF ? 2 * (BN / 4) : BN / 8;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_u32 + (uint32_t)(RING_BYTES + set * CVB + wid_s * 1024));
+        if (tid < NL) {
+            const void* src;
+            if constexpr (LNF) {
+                const int v = tid / (BN / 4), idx = (tid % (BN / 4)) * 4;
+                const float* c2 = p.ln_tab ? p.ln_tab + ((m0n / p.tab_div) % p.tab_mod) * (long)p.Cout : p.ln_c2;
+                src = (v ? c2 : p.ln_c1) + n0n + idx;
+            } else {
+                src = p.bias ? (const void*)((const T*)p.bias + n0n + tid * 8) : (const void*)zero;
+            }
+            lds_dma16_asm(src, dst);
+        }
+    };
     long tile = tile_first;
     if (tile >= ntiles) return;
     init_tile(tile);
     issue(0);
     if (!STAG64 && nph > 1) issue(1);
+    if constexpr (STAG64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(tile), tile_n0(tile), 0);       // the first tile's column vectors (set 0)
+    bool prev_full = false;       // (staggered loop) the previous tile of this workgroup stored all of its rows
     for (;;) {
         const long m0 = tile_m0(tile);
         const int n0 = tile_n0(tile);
         // phase 2 goes into a slot the previous tile's epilogue used: every wave has to be out of it
-        asm volatile("s_barrier" ::: "memory");
+        if constexpr (!STAG64) asm volatile("s_barrier" ::: "memory");
+        if constexpr (STAG64) {
+            cvec = cvec0 + cpar * (CVB / 4);
+        } else
         if constexpr (LNF) {
             // this tile's column vectors -> LDS (read by the epilogue, many barriers from here): threads 0 .. BN/4-1 take c1,
             // the next BN/4 take c2 + the tile's table row (rows of a 256-row tile share one: tab_div % 256 == 0, host-checked)
             if (tid < BN / 2) {
                 const int v = tid / (BN / 4), idx = (tid % (BN / 4)) * 4;
-                f32x4 val = *(const f32x4*)((v ? p.ln_c2 : p.ln_c1) + n0 + idx);
-                if (v && p.ln_tab) val += *(const f32x4*)(p.ln_tab + ((m0 / p.tab_div) % p.tab_mod) * (long)p.Cout + n0 + idx);
-                *(f32x4*)(cvec + v * BN + idx) = val;
+                const float* c2 = p.ln_tab ? p.ln_tab + ((m0 / p.tab_div) % p.tab_mod) * (long)p.Cout : p.ln_c2;      // (table rows include c2)
+                *(f32x4*)(cvec + v * BN + idx) = *(const f32x4*)((v ? c2 : p.ln_c1) + n0 + idx);
             }
         }
-        if constexpr (BIAS_LDS) {
+        if constexpr (BIAS_LDS && !STAG64) {
             // the tile's bias slice -> LDS: the epilogue's five rounds per 32-row block each started with a dependent global
             // load (an L2 round trip the ten-phase K loop of these GEMMs cannot hide)
             if (tid < BN / 8) {
                 const uint4 v = p.bias ? *(const uint4*)((const T*)p.bias + n0 + tid * 8) : uint4{0u, 0u, 0u, 0u};
-                *(f32x4*)(cvec + tid * 8) = f32x4{unpack_lo<T>(v.x), unpack_hi<T>(v.x), unpack_lo<T>(v.y), unpack_hi<T>(v.y)};
-                *(f32x4*)(cvec + tid * 8 + 4) = f32x4{unpack_lo<T>(v.z), unpack_hi<T>(v.z), unpack_lo<T>(v.w), unpack_hi<T>(v.w)};
+                *(uint4*)((char*)cvec + tid * 16) = v;
             }
         }
         if (!STAG64 && nph > 2) issue(2);
@@ -1162,7 +1181,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
             //     t = 4 st + 3 (leading: end of C(st,1); trailing: end of R(st,1)); the first read is at t = 4 st + 4.
             const int grp = wid_s >> 2;
             constexpr int PA = (NPIECE + 1) / 2;           // pieces 0 .. PA-1 in the first of the two request intervals
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage 0 (and the previous epilogue's stores)
+            // Stage 0 was requested in front of the previous tile's epilogue, whose stores are the youngest entries of this wave's
+            // queue.  vmcnt retires in order (hipcc's own counted waits in the epilogue rely on it), so once at most NTAIL entries
+            // remain -- NTAIL below the number of stores every wave issues for a FULL tile -- stage 0 has landed, and the wave does
+            // not sit out the drain of its last stores (3500 - 5000 of a K = 320 tile's 45 000 - 59 000 cycles,
+            // tools/patches/ring_cycle_stamps.patch).  Tiles cut by M store fewer rows: vmcnt(0) behind those.  The same wait makes
+            // this wave's share of the next column vectors (written behind the epilogue) visible after the barrier.
+            constexpr int NTAIL = (EPI == 1 || EPI == 4) ? 6 : 16;
+            if (prev_full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTAIL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
             if (grp) {
                 if (nph > 1 && !(ABL & 1)) static_for<PA>([&](auto ic) { issue_piece(1, ic); });
@@ -1359,6 +1386,8 @@ if (!(ABL & 4))
             init_tile(next);
             issue(0);
             if (!STAG64 && nph > 1) issue(1);
+            // (staggered loop) the next tile's column vectors into the OTHER set
+            if constexpr (STAG64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
         }
         // the epilogue's per-lane addressing (rows / pieces / swizzles of ten store rounds) is invariant across tiles: keep
         // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
@@ -1372,6 +1401,10 @@ if (!(ABL & 4))
         } else
         tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
         if (next >= ntiles) break;
+        if constexpr (STAG64) {
+            cpar ^= 1;
+            prev_full = m0 + BM <= p.M;
+        }
         tile = next;
     }
 }

@@ -504,11 +504,15 @@ def linear(x, w_packed, n, bias=None, res=None, row_stats=False, gn_hw=None):
     return (y, st) if row_stats else y
 
 
-def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1):
+def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1, tab_has_c2=False):
     """Linear(LayerNorm(x)) with the normalisation folded into the GEMM: x [..., K] RAW rows, ``stats`` their statistics
     from the producer (``linear(..., row_stats=True)``), w_packed = pack(gamma (.) W), c1 = row sums of the rounded
-    gamma (.) W, c2 = W beta + bias (fp32 [n]); ``tab`` fp32 [Q, n]: row r also gets tab[(r // tab_div) % Q]."""
+    gamma (.) W, c2 = W beta + bias (fp32 [n]); ``tab`` fp32 [Q, n]: row r also gets tab[(r // tab_div) % Q].
+    The kernel takes table rows that INCLUDE c2 (one column vector per tile, fetched by LDS-DMA): ``tab_has_c2`` says the
+    caller folded it already (``layers.ln_linear`` caches the folded table), otherwise it is added here."""
     _dev(x, w_packed, c1, c2, stats, tab)
+    if tab is not None and not tab_has_c2:
+        tab = (tab + c2[None, :]).contiguous()
     k = x.shape[-1]
     m = x.numel() // k
     assert x.is_contiguous() and w_packed.shape[2] == k and n % 320 == 0

@@ -183,8 +183,9 @@ def ln_linear(norm, weight, bias, x, stats, cache, key, post=None, post_div=1):
     tab = None
     if post is not None:
         # the positional rows added AFTER the normalisation go through the projection once: a [Q, n] fp32 table
-        tab = cache.get(key + "_tab", (weight, post), lambda: (post.float() @ weight.detach().float().t()).contiguous())
-    return kernels.linear_ln(x.contiguous(), wp, c1, c2, stats, norm.eps, n, tab=tab, tab_div=post_div)
+        # (+ c2: the kernel fetches ONE column vector per tile, rows of the table include the constant term)
+        tab = cache.get(key + "_tab", (weight, post, bias, norm.weight, norm.bias), lambda: (post.float() @ weight.detach().float().t() + c2[None, :]).contiguous())
+    return kernels.linear_ln(x.contiguous(), wp, c1, c2, stats, norm.eps, n, tab=tab, tab_div=post_div, tab_has_c2=tab is not None)
 
 
 def _module_cache(mod):

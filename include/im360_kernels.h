@@ -222,10 +222,11 @@ int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, cons
 
 /* Linear(LayerNorm(x)) with the normalisation folded into the GEMM: x [M, K] are the RAW rows, rowstats [M][rs_p][2] their
  * (sum, sum of squares) slices from im360_linear_fwd, w_packed = pack(gamma (.) W) and
- *   y[r] = rstd_r * (x[r] w^T - mu_r * c1) + c2 (+ tab[(r / tab_div) % tab_mod])
+ *   y[r] = rstd_r * (x[r] w^T - mu_r * c1) + (tab ? tab[(r / tab_div) % tab_mod] : c2)
  * with fp32 vectors c1[n] = sum_k w'[n][k] (of the rounded 16-bit w'), c2 = W beta + bias; tab (optional, fp32
- * [tab_mod][N], tab_div % 256 == 0): rows added AFTER the normalisation pushed through the projection (the motion module's
- * frame positional encoding; one table row per 256-row tile).  The LayerNorm pass over the activations and its output tensor do not exist.  Variance = E[x^2] - mu^2 in
+ * [tab_mod][N], tab_div % 256 == 0): c2 + the rows added AFTER the normalisation pushed through the projection (the motion
+ * module's frame positional encoding; one table row per 256-row tile; since round 4 the rows INCLUDE c2, so that a tile's
+ * constant term is one vector the kernel fetches by LDS-DMA).  The LayerNorm pass over the activations and its output tensor do not exist.  Variance = E[x^2] - mu^2 in
  * fp32 from 16-bit data.  N % 320 == 0, K % 32 == 0.
  * Replaces: nn.LayerNorm -> to_q / fused to_q,k,v, animatediff/models/attention.py:470-488; motion_module.py:236-250
  *   (+ pos_encoder :349-350). */

@@ -191,11 +191,11 @@ def _row_affine(x, w_packed, rows, c1, c2, stats, eps):
     return (acc - mu[:, None] * c1[None]) * rstd[:, None] + c2[None]
 
 
-def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1):
+def linear_ln(x, w_packed, c1, c2, stats, eps, n, tab=None, tab_div=1, tab_has_c2=False):
     y = _row_affine(x, w_packed, n, c1, c2, stats, eps)
     if tab is not None:
         r = torch.arange(y.shape[0])
-        y = y + tab[(r // tab_div) % tab.shape[0]]
+        y = y + (tab - c2[None, :] if tab_has_c2 else tab)[(r // tab_div) % tab.shape[0]]
     return y.to(x.dtype).reshape(x.shape[:-1] + (n,))
 
 
