@@ -101,6 +101,55 @@ __device__ __forceinline__ bool epi_round_rc(int it, int lane, int& row, int& pc
 }
 template <int PIECES, bool GNS>
 constexpr int epi_rounds() { return GNS ? (32 + 64 / PIECES - 1) / (64 / PIECES) : (32 * PIECES) / 64; }
+// EPI 3 (LayerNorm folded into the projection): mean / rstd of this lane's row in each of the wave's TM blocks from the producer's
+// per-slice (sum, sum of squares).  All slices of both rows are requested before the first is added (2 / 4 / 8 slices unrolled: a
+// run-time loop waits for each load in turn); the persistent kernel calls this right behind its K loop, BEFORE the next tile's
+// first LDS-DMA requests: hipcc's wait for these loads is vmcnt(0) -- it does not see the asm requests -- and behind them it would
+// also wait for a stage that was requested a moment ago.
+template <int TM>
+__device__ __forceinline__ void epi_ln_row_stats(const ConvParams& p, long m0, int wm, int col, float (&mus)[TM], float (&rstds)[TM]) {
+    float ss[TM], qq[TM];
+    const float* rows[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const long mr = m0 + wm * (TM * 32) + b * 32 + col;
+        rows[b] = p.rs_in + (mr < p.M ? mr : p.M - 1) * p.rs_p * 2;
+        ss[b] = qq[b] = 0.f;
+    }
+    auto sum_n = [&](auto nc) {
+        constexpr int NS = decltype(nc)::value;
+        f32x2 v[TM][NS];
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) v[b][j] = *(const f32x2*)(rows[b] + j * 2);
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                ss[b] += v[b][j].x;
+                qq[b] += v[b][j].y;
+            }
+    };
+    if (p.rs_p == 2) sum_n(std::integral_constant<int, 2>{});
+    else if (p.rs_p == 4) sum_n(std::integral_constant<int, 4>{});
+    else if (p.rs_p == 8) sum_n(std::integral_constant<int, 8>{});
+    else {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+            for (int j = 0; j < p.rs_p; ++j) {
+                const f32x2 v = *(const f32x2*)(rows[b] + j * 2);
+                ss[b] += v.x;
+                qq[b] += v.y;
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        mus[b] = ss[b] * p.ln_invc;
+        rstds[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - mus[b] * mus[b], 0.f) + p.ln_eps);
+    }
+}
+
 // RESM: 0 = residual known at run time only (its loads are unconditional: an absent one reads the zero chunk); 1 = residual
 // present; 2 = no residual: the row-major pass moves whole 16-byte pieces LDS -> memory without unpacking them.  Round 4
 // (tools/patches/ring_cycle_stamps.patch: cycle stamps of one workgroup): the plain epilogue of a 256 x 320 tile takes 14 000
@@ -114,7 +163,8 @@ constexpr int epi_rounds() { return GNS ? (32 + 64 / PIECES - 1) / (64 / PIECES)
 // Same arithmetic in all three: identical values (RESM 2 keeps the sign of a zero that x + 0 would clear).
 template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2, int RESM = 0>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
-                                              int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0) {
+                                              int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0,
+                                              const float* ln_pre = nullptr) {
     const int col = lane & 31, hi = lane >> 5;
     const T* bias = (const T*)p.bias;
     const T* temb = (const T*)p.temb;
@@ -273,22 +323,14 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         // producer's per-slice (sum, sum of squares), all requested up front (one memory latency per tile, not one per block)
         float ln_mus[EPI == 3 ? TM : 1], ln_rstds[EPI == 3 ? TM : 1];
         if constexpr (EPI == 3) {
-            float ss[TM], qq[TM];
+            if (ln_pre) {                 // (the persistent kernel computed them behind its K loop: [mu_0 .. mu_TM-1, rstd_0 ..])
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const long mr = m0 + wm * (TM * 32) + b * 32 + col;
-                const long mrow = mr < p.M ? mr : p.M - 1;
-                ss[b] = qq[b] = 0.f;
-                for (int j = 0; j < p.rs_p; ++j) {
-                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
-                    ss[b] += v.x;
-                    qq[b] += v.y;
+                for (int b = 0; b < TM; ++b) {
+                    ln_mus[b] = ln_pre[b];
+                    ln_rstds[b] = ln_pre[TM + b];
                 }
-            }
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                ln_mus[b] = ss[b] * p.ln_invc;
-                ln_rstds[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - ln_mus[b] * ln_mus[b], 0.f) + p.ln_eps);
+            } else {
+                epi_ln_row_stats<TM>(p, m0, wm, col, ln_mus, ln_rstds);
             }
         }
         constexpr int NIT = epi_rounds<PIECES, GNS>(), NIT1 = NIT / 2;
@@ -1380,6 +1422,16 @@ if (!(ABL & 4))
             __builtin_amdgcn_sched_barrier(0);
         }
         }
+        float ln_pre[2 * TM];
+        if constexpr (EPI == 3) {
+            float mus[TM], rstds[TM];
+            epi_ln_row_stats<TM>(p, m0, wid_s / WN, lane & 31, mus, rstds);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                ln_pre[b] = mus[b];
+                ln_pre[TM + b] = rstds[b];
+            }
+        }
         asm volatile("s_barrier" ::: "memory");          // every wave is done reading operand slots
         const long next = tile + tile_step;
         if (next < ntiles) {                             // keep the operand stream going under the epilogue
@@ -1399,7 +1451,7 @@ if (!(ABL & 4))
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN);
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN, EPI == 3 ? ln_pre : nullptr);
         if (next >= ntiles) break;
         if constexpr (STAG64) {
             cpar ^= 1;
