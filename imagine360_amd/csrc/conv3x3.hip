@@ -211,22 +211,14 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         // requested up front (one memory latency for the tile instead of one per block).
         float ln_mu[TM], ln_rs[TM];
         if constexpr (EPI == 4) {
-            float ss[TM], qq[TM];
+            if (ln_pre) {                 // (the persistent kernel computed them behind its K loop, see epi_ln_row_stats)
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const long mr = m0 + wm * (TM * 32) + b * 32 + col;
-                const long mrow = mr < p.M ? mr : p.M - 1;
-                ss[b] = qq[b] = 0.f;
-                for (int j = 0; j < p.rs_p; ++j) {
-                    const f32x2 v = *(const f32x2*)(p.rs_in + (mrow * p.rs_p + j) * 2);
-                    ss[b] += v.x;
-                    qq[b] += v.y;
+                for (int b = 0; b < TM; ++b) {
+                    ln_mu[b] = ln_pre[b];
+                    ln_rs[b] = ln_pre[TM + b];
                 }
-            }
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                ln_mu[b] = ss[b] * p.ln_invc;
-                ln_rs[b] = __builtin_amdgcn_rsqf(fmaxf(qq[b] * p.ln_invc - ln_mu[b] * ln_mu[b], 0.f) + p.ln_eps);
+            } else {
+                epi_ln_row_stats<TM>(p, m0, wm, col, ln_mu, ln_rs);
             }
         }
 #pragma unroll
@@ -1423,7 +1415,7 @@ if (!(ABL & 4))
         }
         }
         float ln_pre[2 * TM];
-        if constexpr (EPI == 3) {
+        if constexpr (EPI == 3 || EPI == 4) {
             float mus[TM], rstds[TM];
             epi_ln_row_stats<TM>(p, m0, wid_s / WN, lane & 31, mus, rstds);
 #pragma unroll
@@ -1451,7 +1443,7 @@ if (!(ABL & 4))
 #pragma unroll
                 for (int b = 0; b < TM; ++b) keep_alive(acc[a][b]);
         } else
-        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN, EPI == 3 ? ln_pre : nullptr);
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN, (EPI == 3 || EPI == 4) ? ln_pre : nullptr);
         if (next >= ntiles) break;
         if constexpr (STAG64) {
             cpar ^= 1;
