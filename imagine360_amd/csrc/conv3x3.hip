@@ -971,8 +971,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     const long ntiles = p.nblocks / p.ngroups;              // tiles of one group, index j = pixel tile * tn_g + local cout tile
     const long tile_first = (long)((blockIdx.x % 8) % xg_n) * per_xcd + blockIdx.x / 8;
     const long tile_step = (long)xg_n * per_xcd;
-    auto tile_m0 = [&](long j) { return (j / tn_g) * BM; };
-    auto tile_n0 = [&](long j) { return (grp * tn_g + (int)(j % tn_g)) * BN; };
+    // (tile indices fit 32 bits -- the launcher refuses more -- and a 64-bit scalar division is ~ 100 instructions, paid three
+    //  times per tile boundary)
+    auto tile_m0 = [&](long j) { return (long)((uint32_t)j / (uint32_t)tn_g) * BM; };
+    auto tile_n0 = [&](long j) { return (grp * tn_g + (int)((uint32_t)j % (uint32_t)tn_g)) * BN; };
 
     constexpr int RPI = NT / CPR;               // 128 tile rows between a thread's consecutive chunks
     const int srow = tid / CPR;
@@ -1762,6 +1764,10 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     constexpr int BM = 256, BN = 2 * TN * 32;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (p.nblocks > 0x7fffffffL) {                // (the kernel divides tile indices in 32 bits)
+        im360_set_error("linear_fwd / conv_fwd: problem too large");
+        return IM360_ERR_ARG;
+    }
     static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
