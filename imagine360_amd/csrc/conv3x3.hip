@@ -926,11 +926,14 @@ template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
     constexpr bool STAG64 = (MODE & 15) == 3;
-    constexpr int ABL = MODE >> 4;                       // ablation builds of the loop (tools/ab_stag.py --ablate): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads                   // 64-channel stages in two buffers, staggered wave groups (below)
-    constexpr int BM = 256, BN = WN * TN * 32, BK = STAG64 ? 64 : 32;
+    constexpr bool PLAIN64 = (MODE & 15) == 4;           // 64-channel stages in two buffers, conv_igemm_kernel's loop (one barrier per stage) in this persistent shell
+    constexpr bool BK64 = STAG64 || PLAIN64;
+    constexpr int ABL = (MODE >> 4) & 7;                 // ablation builds of the loop (tools/ab_stag.py --ablate): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
+    constexpr bool CMK = !LINEAR && (MODE & 128) != 0;   // 3 x 3 convolution with the taps innermost (conv_igemm_kernel's CM producer: same K order, same bits)                   // 64-channel stages in two buffers, staggered wave groups (below)
+    constexpr int BM = 256, BN = WN * TN * 32, BK = BK64 ? 64 : 32;
     constexpr int CPR = BK / 8, ROWB = BK * 2, RPB = 256 / ROWB;      // 4 chunks per 64-byte row, 4 rows per bank row (8 / 2 at 64 channels)
     constexpr int KC = BK / 16;
-    constexpr int NSLOT = STAG64 ? 2 : 4;
+    constexpr int NSLOT = BK64 ? 2 : 4;
     constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB, SLOT = TILE_A + TILE_B;
     constexpr int LDA = (BM * CPR) / NT;                  // 2 LDS-DMA loads per thread per phase: activations
     constexpr int LDB = (BN * CPR) / NT;                  // 2 full rounds of weights ...
@@ -938,13 +941,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     static_assert((BM * CPR) % NT == 0 && ((BN * CPR) % NT == 0 || (BN * CPR) % NT == NT / 2), "staging pattern");
     constexpr int EPI_ROWB = (EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64;
     constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB;
-    constexpr int EPI_OFF = STAG64 ? SLOT : 2 * SLOT;          // the epilogue's staging starts behind the slots the next tile is prefetched into
+    constexpr int EPI_OFF = BK64 ? SLOT : 2 * SLOT;          // the epilogue's staging starts behind the slots the next tile is prefetched into
     constexpr int RING_BYTES = NSLOT * SLOT > EPI_OFF + EPI_BYTES ? NSLOT * SLOT : EPI_OFF + EPI_BYTES;
     constexpr bool LNF = EPI == 3 || EPI == 4;                 // LayerNorm-folded epilogues: the tile's fp32 column vectors c1 | c2 live in LDS
     constexpr bool BIAS_LDS = EPI == 2 || EPI == 5;            // token-major Linears: the tile's bias slice lives in LDS (T-typed, BN entries)
     constexpr int CVB = LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0);       // bytes of one tile's column vectors
     // (staggered loop: TWO sets -- the next tile's are loaded before and written behind this tile's epilogue, see the tile boundary)
-    constexpr int LDS_BYTES = RING_BYTES + (STAG64 ? 2 : 1) * CVB;
+    constexpr int LDS_BYTES = RING_BYTES + (BK64 ? 2 : 1) * CVB;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     float* const cvec0 = (float*)(lds + RING_BYTES);
@@ -990,6 +993,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     const T* bptr = wg;
     const long bstride = (long)RPI * p.ntaps * p.Cin;
     int tap_p = 0, kk_p = 0;
+    // CMK: the centre pixel's pointer per slot (aptr), nine validity bits per slot, wave-uniform element offsets of the current tap
+    // (relative to the centre) and of the current channel chunk -- see conv_igemm_kernel
+    uint32_t vmask[CMK ? LDA : 1];
+    long tapdelta = 0, kofs = 0;
     auto set_tap = [&](int tap) {
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
 #pragma unroll
@@ -1022,6 +1029,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 aptr[i] = ok ? xg + m * p.Cin + pd8 : zero;
                 amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
             }
+        } else if constexpr (CMK) {
+#pragma unroll
+            for (int i = 0; i < LDA; ++i) {
+                const long m = m0 + srow + i * RPI;
+                const bool valid = m < p.M;
+                const uint32_t mm = valid ? (uint32_t)m : 0u;          // (pixel indices fit 32 bits: host-checked)
+                const uint32_t t = mm / (uint32_t)p.Wout;
+                const int cy = (int)(t % (uint32_t)p.Hout) * p.stride + p.y_off, cx = (int)(mm % (uint32_t)p.Wout) * p.stride + p.x_off;
+                uint32_t vm = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int gy = cy + tp / 3 - 1, gx = cx + tp % 3 - 1;
+                    vm |= (gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) ? (1u << tp) : 0u;
+                }
+                vmask[i] = valid ? vm : 0u;
+                aptr[i] = valid ? xg + (((long)(t / (uint32_t)p.Hout) * p.Hin + cy) * p.Win + cx) * p.Cin + pd8 : xg;
+            }
+            tapdelta = -(long)(p.Win + 1) * p.Cin;          // tap 0 = (dy, dx) = (-1, -1)
+            kofs = 0;
         } else {
 #pragma unroll
             for (int i = 0; i < LDA; ++i) {
@@ -1051,9 +1077,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int abase = slot * SLOT + wid_s * 1024;
         const int bbase = abase + TILE_A;
         if constexpr (i < LDA) {
-            dma(aptr[i], abase + i * (NT * 16));
-            aptr[i] += ((amask >> i) & 1u) ? BK : 0;
+            if constexpr (CMK) {
+                dma(((vmask[i] >> tap_p) & 1u) ? aptr[i] + (tapdelta + kofs) : zero, abase + i * (NT * 16));
+            } else {
+                dma(aptr[i], abase + i * (NT * 16));
+                aptr[i] += ((amask >> i) & 1u) ? BK : 0;
+            }
         } else if constexpr (i < LDA + LDB) {
+            if constexpr (CMK) dma(bptr + (i - LDA) * bstride + ((long)tap_p * p.Cin + kofs), bbase + (i - LDA) * (NT * 16));
+            else
             dma(bptr + (i - LDA) * bstride, bbase + (i - LDA) * (NT * 16));
         } else {
             // rows 256 .. 319 of the weight tile: one more KiB for each of the first four waves
@@ -1061,6 +1093,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
     };
     auto issue_advance = [&]() {
+        if constexpr (CMK) {
+            ++tap_p;
+            tapdelta += p.Cin;
+            if (tap_p == 3 || tap_p == 6) tapdelta += (long)(p.Win - 3) * p.Cin;
+            if (tap_p == 9) {
+                tap_p = 0;
+                tapdelta = -(long)(p.Win + 1) * p.Cin;
+                kofs += BK;
+            }
+            return;
+        }
         bptr += BK;
         if constexpr (!LINEAR) {
             if (++kk_p == ksteps_per_tap) {
@@ -1118,15 +1161,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     if (tile >= ntiles) return;
     init_tile(tile);
     issue(0);
-    if (!STAG64 && nph > 1) issue(1);
-    if constexpr (STAG64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(tile), tile_n0(tile), 0);       // the first tile's column vectors (set 0)
+    if (!BK64 && nph > 1) issue(1);
+    if constexpr (BK64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(tile), tile_n0(tile), 0);       // the first tile's column vectors (set 0)
     bool prev_full = false;       // (staggered loop) the previous tile of this workgroup stored all of its rows
     for (;;) {
         const long m0 = tile_m0(tile);
         const int n0 = tile_n0(tile);
         // phase 2 goes into a slot the previous tile's epilogue used: every wave has to be out of it
-        if constexpr (!STAG64) asm volatile("s_barrier" ::: "memory");
-        if constexpr (STAG64) {
+        if constexpr (!BK64) asm volatile("s_barrier" ::: "memory");
+        if constexpr (BK64) {
             cvec = cvec0 + cpar * (CVB / 4);
         } else
         if constexpr (LNF) {
@@ -1138,7 +1181,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 *(f32x4*)(cvec + v * BN + idx) = *(const f32x4*)((v ? c2 : p.ln_c1) + n0 + idx);
             }
         }
-        if constexpr (BIAS_LDS && !STAG64) {
+        if constexpr (BIAS_LDS && !BK64) {
             // the tile's bias slice -> LDS: the epilogue's five rounds per 32-row block each started with a dependent global
             // load (an L2 round trip the ten-phase K loop of these GEMMs cannot hide)
             if (tid < BN / 8) {
@@ -1146,7 +1189,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 *(uint4*)((char*)cvec + tid * 16) = v;
             }
         }
-        if (!STAG64 && nph > 2) issue(2);
+        if (!BK64 && nph > 2) issue(2);
 
         f32x16 acc[TN][TM];
 #pragma unroll
@@ -1310,6 +1353,48 @@ if (!(ABL & 4))
                 asm volatile("s_barrier" ::: "memory");
             }
             if (!grp) asm volatile("s_barrier" ::: "memory");         // the leading group waits for the trailing one: aligned again
+        } else if constexpr (PLAIN64) {
+            // conv_igemm_kernel's K loop (a stage of 64 channels per barrier, the next stage requested right behind the barrier, the
+            // fragments of 16-channel chunk kc + 1 fetched while the MFMAs of chunk kc run: 48 fragment registers, which leaves room
+            // for the chunk-major convolution producer) inside this kernel's persistent shell: the next tile's first stage and column
+            // data are requested under the epilogue, no workgroup turnover between tiles, the tile-start wait leaves the last
+            // stores in flight.  Same accumulation order as every other loop.
+            constexpr int NTAIL = (EPI == 1 || EPI == 4) ? 6 : 16;
+            if (prev_full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTAIL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            for (int st = 0; st < nph; ++st) {
+                if (st > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");       // stage st landed for every wave; buffer (st + 1) & 1 is free again
+                }
+                if (st + 1 < nph) issue((st + 1) & 1);
+                const char* at = lds + (st & 1) * SLOT;
+                constexpr int LATE = TN >= 4 ? 2 : 0;
+                u32x4 wf[2][TN - LATE], xf[2][TM], wl[LATE ? LATE : 1];
+                auto fetch = [&](auto kcc) {
+                    constexpr int kc = decltype(kcc)::value;
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) xf[kc & 1][b] = *(const u32x4*)(at + xrow + koff[kc] + b * (32 * ROWB));
+#pragma unroll
+                    for (int a = 0; a < TN - LATE; ++a) wf[kc & 1][a] = *(const u32x4*)(at + wrow + koff[kc] + a * (32 * ROWB));
+                };
+                fetch(std::integral_constant<int, 0>{});
+                static_for<KC>([&](auto kcc) {
+                    constexpr int kc = decltype(kcc)::value;
+#pragma unroll
+                    for (int a = 0; a < LATE; ++a) wl[a] = *(const u32x4*)(at + wrow + koff[kc] + (TN - LATE + a) * (32 * ROWB));
+                    if constexpr (kc + 1 < KC) fetch(std::integral_constant<int, kc + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b)
+                            acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, a < TN - LATE ? wf[kc & 1][a < TN - LATE ? a : 0] : wl[a >= TN - LATE ? a - (TN - LATE) : 0]),
+                                                        __builtin_bit_cast(uint4, xf[kc & 1][b]), acc[a][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         } else if constexpr (MODE == 2) {
             // The LDS-DMA path of a CU moves ~21 B/clk: a wave that issues its 4-5 KiB of a phase back to back sits in
             // the issue queue for most of a phase while its MFMAs wait behind it (ablation: DMA-only and MFMA-only loop
@@ -1431,9 +1516,9 @@ if (!(ABL & 4))
         if (next < ntiles) {                             // keep the operand stream going under the epilogue
             init_tile(next);
             issue(0);
-            if (!STAG64 && nph > 1) issue(1);
+            if (!BK64 && nph > 1) issue(1);
             // (staggered loop) the next tile's column vectors into the OTHER set
-            if constexpr (STAG64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
+            if constexpr (BK64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
         }
         // the epilogue's per-lane addressing (rows / pieces / swizzles of ten store rounds) is invariant across tiles: keep
         // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
@@ -1447,7 +1532,7 @@ if (!(ABL & 4))
         } else
         tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN, (EPI == 3 || EPI == 4) ? ln_pre : nullptr);
         if (next >= ntiles) break;
-        if constexpr (STAG64) {
+        if constexpr (BK64) {
             cpar ^= 1;
             prev_full = m0 + BM <= p.M;
         }
@@ -1806,6 +1891,21 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
             else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 2>), dim3(grid), dim3(512), 0, stream, p);
         }
     };
+#ifdef IM360_ABLATE
+    if constexpr (!LINEAR && TN == 5 && EPI == 0) {
+        if (variant == 9) {                     // 3 x 3 convolution, taps innermost, on the plain 64-channel loop in the persistent shell (the caller checked that the order applies)
+            if (p.gn_out) {
+                if (p.res) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 4 + 128, true, 1>), dim3(grid), dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 4 + 128, true, 2>), dim3(grid), dim3(512), 0, stream, p);
+            } else {
+                if (p.res) hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 4 + 128, false, 1>), dim3(grid), dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 4 + 128, false, 2>), dim3(grid), dim3(512), 0, stream, p);
+            }
+            IM360_CHECK_LAUNCH();
+            return IM360_OK;
+        }
+    }
+#endif
     if constexpr (LINEAR && TN == 5 && (EPI == 2 || EPI == 5)) {
         if (p.gn_out) {                         // GroupNorm partial sums from the epilogue (see ConvParams::gn_out)
             if (stag) launch_stag(std::true_type{});
@@ -1908,6 +2008,16 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 #endif
         // measured (tools/ab_ring.py, profiles/README.md): the persistent ring kernel wins 3-8 % on the token-major GEMMs
         // (short K, epilogue-heavy) and loses 1-8 % on the deep-K convolutions; knob value 5 forces it for both
+#ifdef IM360_ABLATE
+        // round 4, measured and not shipped: 3 x 3 convolutions with the taps innermost on the PERSISTENT kernel (next tile's first
+        // stage requested under the epilogue, no workgroup turnover between tiles; knob conv_persist).  Identical bits on nine
+        // shapes incl. stride 2 and the statistics epilogue, but 0.93 - 1.04 x conv_igemm_kernel's speed (profiles/r04_conv_persist_ab.log):
+        // the shell's state next to the chunk-major producer's puts ~ 20 registers into scratch, and a scratch reload inside the K
+        // loop is a VMEM load whose wait also waits for the stage requested in front of it.  A register diet (32-bit pixel offsets,
+        // packed validity bits) is the next step.
+        if (knob(KNOB_CONV_PERSIST) && !linear && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && !p.x2 && p.Cin % 64 == 0 && knob(KNOB_CONV_BK) != 32 && p.M <= 0x7fffffffL)
+            return launch_ring_t<T, 5, 0, false>(p, stream, 9);
+#endif
         if (p.gn_out && !linear) return launch_conv_t<T, 4, 2, 2, 5>(p, stream);
         if (ring_env && linear) return launch_ring_t<T, 5, 2, true>(p, stream, ring_env == 5 ? 1 : (ring_env == 7 ? 6 : ring_env));
         if (ring_env >= 5) return launch_ring_t<T, 5, 0, false>(p, stream, ring_env == 7 ? 6 : 1);

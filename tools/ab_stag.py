@@ -57,13 +57,14 @@ if "--conv" in sys.argv:
         fl = 2.0 * N * H * W * Cin * Cout * 9 / (kw.get("stride", 1) ** 2)
         rowtxt, ys = [], []
         for v in (0, 1):
-            K.tuning_set("conv_stag", v)
+            K.tuning_set("conv_persist" if "--persist" in sys.argv else "conv_stag", v)
             y = K.conv2d(x, wp, Cout, bias=b, **kw)
             g = K._gn_of(y)
             ys.append((y.clone(), None if g is None else g[0].clone()))
             t = timeit(lambda: K.conv2d(x, wp, Cout, bias=b, **kw), iters)
             rowtxt.append(f"stag {v}: {t * 1e3:7.3f} ms {fl / t / 1e12:6.0f} TF/s")
         K.tuning_set("conv_stag", 0)
+        K.tuning_set("conv_persist", 0)
         same = torch.equal(ys[0][0], ys[1][0]) and (ys[0][1] is None or torch.equal(ys[0][1], ys[1][1]))
         print(f"conv {name:24s} " + " | ".join(rowtxt) + f" | identical {same}", flush=True)
 if "--ablate" in sys.argv:
