@@ -517,6 +517,36 @@ def test_gemm_pipeline_variants_are_bit_identical(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("knob", ["conv_stag", "conv_persist"])
+def test_conv_loop_variants_of_the_ablation_build_are_bit_identical(dt, knob):
+    """Round 4's two rejected loops for the 3x3 convolutions (make ablate): staggered wave groups inside conv_igemm_kernel
+    (conv_stag) and the chunk-major producer on the persistent shell (conv_persist) accumulate in the default kernel's order:
+    identical outputs and GroupNorm partial sums, with time embedding + residual, stride 2, and a ragged image count."""
+    if not K.ablate_build():
+        pytest.skip("variants are compiled by `make ablate` only")
+    g = torch.Generator().manual_seed(62)
+    cases = [(160, 32, 32, 320, 320, dict()), (160, 32, 32, 128, 640, dict(stride=2)), (161, 16, 16, 64, 320, dict())]
+    for N, H, W, Cin, Cout, kw in cases:
+        x = torch.randn(N, H, W, Cin, generator=g).to(dt).cuda()
+        wp = K.pack_conv_weight((torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dt).cuda())
+        b = torch.randn(Cout, generator=g).to(dt).cuda()
+        st = kw.get("stride", 1)
+        temb = torch.randn(N, Cout, generator=g).to(dt).cuda()
+        res = torch.randn(N, H // st, W // st, Cout, generator=g).to(dt).cuda()
+        outs = []
+        try:
+            for v in (0, 1):
+                K.tuning_set(knob, v)
+                y = K.conv2d(x, wp, Cout, bias=b, temb=temb, res=res, gn_stats=True, **kw)
+                gn = K._gn_of(y)
+                outs.append((y.clone(), None if gn is None else gn[0].clone()))
+        finally:
+            K.tuning_set(knob, 0)
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert (outs[0][1] is None) == (outs[1][1] is None) and (outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,Kd", [(131073, 320), (65536 + 77, 64), (70000, 1280)])
 def test_staggered_gemm_loop_every_epilogue_bit_identical_to_the_ring(dt, M, Kd):
     """Round 4's default loop of the token-major GEMMs (64-channel stages in two buffers, two wave groups one barrier interval

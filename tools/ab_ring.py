@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the conv / GEMM pipelines on the MI355X: two-stage kernel (knob conv_ring = 0) vs the persistent ring kernel
+"""(Round 2 / 3 tool; since round 4 knob conv_ring 1 selects the staggered 64-channel-stage loop for the token-major GEMMs and 8 the
+ring with interleaved requests this tool was written around -- see tools/ab_stag.py for the current A/B.)
+A/B of the conv / GEMM pipelines on the MI355X: two-stage kernel (knob conv_ring = 0) vs the persistent ring kernel
 (1: asm LDS-DMA, 2: builtin LDS-DMA).  Checks that all variants return IDENTICAL tensors (same accumulation order) and
 prints their times at cfg2 shapes.
 
