@@ -996,7 +996,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     // CMK: the centre pixel's pointer per slot (aptr), nine validity bits per slot, wave-uniform element offsets of the current tap
     // (relative to the centre) and of the current channel chunk -- see conv_igemm_kernel
     uint32_t vmask[CMK ? LDA : 1];
-    long tapdelta = 0, kofs = 0;
+    int tapdelta = 0, kofs = 0;         // (32-bit and pinned to SGPRs by readfirstlane at every update: as 64-bit values hipcc kept them
+                                        //  in VGPR pairs, spilled one and reloaded it -- a VMEM load -- inside the K loop)
     auto set_tap = [&](int tap) {
         const int dy = p.ntaps == 9 ? tap / 3 : 1, dx = p.ntaps == 9 ? tap % 3 : 1;
 #pragma unroll
@@ -1046,7 +1047,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                 vmask[i] = valid ? vm : 0u;
                 aptr[i] = valid ? xg + (((long)(t / (uint32_t)p.Hout) * p.Hin + cy) * p.Win + cx) * p.Cin + pd8 : xg;
             }
-            tapdelta = -(long)(p.Win + 1) * p.Cin;          // tap 0 = (dy, dx) = (-1, -1)
+            tapdelta = __builtin_amdgcn_readfirstlane(-(p.Win + 1) * p.Cin);          // tap 0 = (dy, dx) = (-1, -1)
             kofs = 0;
         } else {
 #pragma unroll
@@ -1078,13 +1079,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
         const int bbase = abase + TILE_A;
         if constexpr (i < LDA) {
             if constexpr (CMK) {
-                dma(((vmask[i] >> tap_p) & 1u) ? aptr[i] + (tapdelta + kofs) : zero, abase + i * (NT * 16));
+                dma(((vmask[i] >> tap_p) & 1u) ? aptr[i] + (long)(tapdelta + kofs) : zero, abase + i * (NT * 16));
             } else {
                 dma(aptr[i], abase + i * (NT * 16));
                 aptr[i] += ((amask >> i) & 1u) ? BK : 0;
             }
         } else if constexpr (i < LDA + LDB) {
-            if constexpr (CMK) dma(bptr + (i - LDA) * bstride + ((long)tap_p * p.Cin + kofs), bbase + (i - LDA) * (NT * 16));
+            if constexpr (CMK) dma(bptr + (i - LDA) * bstride + (long)(tap_p * p.Cin + kofs), bbase + (i - LDA) * (NT * 16));
             else
             dma(bptr + (i - LDA) * bstride, bbase + (i - LDA) * (NT * 16));
         } else {
@@ -1094,14 +1095,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     };
     auto issue_advance = [&]() {
         if constexpr (CMK) {
-            ++tap_p;
-            tapdelta += p.Cin;
-            if (tap_p == 3 || tap_p == 6) tapdelta += (long)(p.Win - 3) * p.Cin;
-            if (tap_p == 9) {
-                tap_p = 0;
-                tapdelta = -(long)(p.Win + 1) * p.Cin;
-                kofs += BK;
+            int tp = tap_p + 1, td = tapdelta + p.Cin, ko = kofs;
+            if (tp == 3 || tp == 6) td += (p.Win - 3) * p.Cin;
+            if (tp == 9) {
+                tp = 0;
+                td = -(p.Win + 1) * p.Cin;
+                ko += BK;
             }
+            tap_p = __builtin_amdgcn_readfirstlane(tp);
+            tapdelta = __builtin_amdgcn_readfirstlane(td);
+            kofs = __builtin_amdgcn_readfirstlane(ko);
             return;
         }
         bptr += BK;
@@ -2011,10 +2014,10 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 #ifdef IM360_ABLATE
         // round 4, measured and not shipped: 3 x 3 convolutions with the taps innermost on the PERSISTENT kernel (next tile's first
         // stage requested under the epilogue, no workgroup turnover between tiles; knob conv_persist).  Identical bits on nine
-        // shapes incl. stride 2 and the statistics epilogue, but 0.93 - 1.04 x conv_igemm_kernel's speed (profiles/r04_conv_persist_ab.log):
-        // the shell's state next to the chunk-major producer's puts ~ 20 registers into scratch, and a scratch reload inside the K
-        // loop is a VMEM load whose wait also waits for the stage requested in front of it.  A register diet (32-bit pixel offsets,
-        // packed validity bits) is the next step.
+        // shapes incl. stride 2 and the statistics epilogue.  First form 0.93 - 1.04 x conv_igemm_kernel's speed: hipcc kept the 64-bit
+        // tap / chunk offsets in VGPR pairs, spilled one and reloaded it inside the K loop -- a scratch reload is a VMEM load whose
+        // wait also waits for the stage requested in front of it.  With the offsets 32-bit and pinned to SGPRs the loop is clean and
+        // the kernel TIES: 0.96 - 1.05 x (profiles/r04_conv_persist_ab.log) -- workgroup turnover is not what the convolutions lose.
         if (knob(KNOB_CONV_PERSIST) && !linear && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && !p.x2 && p.Cin % 64 == 0 && knob(KNOB_CONV_BK) != 32 && p.M <= 0x7fffffffL)
             return launch_ring_t<T, 5, 0, false>(p, stream, 9);
 #endif
