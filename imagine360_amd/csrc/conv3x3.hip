@@ -1518,10 +1518,12 @@ if (!(ABL & 4))
         const long next = tile + tile_step;
         if (next < ntiles) {                             // keep the operand stream going under the epilogue
             init_tile(next);
+            // (staggered loop) the next tile's column vectors into the OTHER set -- IN FRONT of the stage requests: its address
+            // comes back from scratch in some instantiations, and the wait of that reload would also wait for a stage requested
+            // a moment ago (the wave that fills the vectors then starts its epilogue a memory latency late)
+            if constexpr (BK64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
             issue(0);
             if (!BK64 && nph > 1) issue(1);
-            // (staggered loop) the next tile's column vectors into the OTHER set
-            if constexpr (BK64 && (LNF || BIAS_LDS)) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
         }
         // the epilogue's per-lane addressing (rows / pieces / swizzles of ten store rounds) is invariant across tiles: keep
         // the compiler from hoisting ~40 registers of it out of the tile loop (they would be spilled around the K loop)
