@@ -1545,6 +1545,278 @@ if (!(ABL & 4))
     }
 }
 
+// ---- token-major GEMM with TWO activation stages in flight ("A3", round 4, knob conv_ring 10) -----------------------------
+// The staggered loop above holds two 64-channel stages of both operands, so ONE is in flight while the other is consumed, and a
+// stage needs longer to arrive (1.1 - 2 us) than its MFMAs take (1.07 us): the loop runs at 53 - 65 % of the matrix rate
+// (cycle stamps).  The activation rows are what comes from HBM / the Infinity Cache; the weight rows hit the L2.
+// Here the activation tile gets THREE 64-channel buffers (two stages in flight) and the weight tile three HALF stages of 32
+// channels (64-byte row segments: half the L2 path's efficiency on 5/9 of the bytes, still below the MFMA time) -- 156 KB:
+//   LDS map: A0 | B0 | B1 | A1 | A2 | B2; the next tile's A0 / B0 / B1 are requested under the epilogue, which stages through A1 ..
+// Intervals as in MODE 3 (R fetches the fragments of two 16-channel chunks, C runs their 20 MFMAs; the wave groups one interval
+// apart).  In absolute intervals t (stage st: 4 st .. 4 st + 3):
+//   t = 4 st      requests B half 2 st + 2 (slot of half 2 st - 1, last read at 4 st - 1), then A stage st + 2 (slot of st - 1)
+//   t = 4 st + 2  requests B half 2 st + 3 (slot of half 2 st, last read at 4 st + 1)
+//   end of 4 st + 1: B half 2 st + 1 has to be in LDS for every wave; end of 4 st + 3: B half 2 st + 2 and A stage st + 1
+// (leading group: requests in its R intervals, waits at the end of its C intervals; trailing group: requests between the MFMAs of
+// its C intervals one interval earlier in its own frame, waits at the end of its R intervals).  vmcnt retires in order, so each
+// wait names how many YOUNGER requests may stay in flight: the B half always goes out in front of the A stage of the same
+// interval, and A (st + 2) stays in flight across both waits of stage st.  Same accumulation order as every other loop.
+template <typename T, int TN, int EPI, bool GNS = false, int RESM = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_a3_kernel(ConvParams p) {
+    constexpr int NT = 512, WN = 2, TM = 2, BM = 256, BN = WN * TN * 32;
+    constexpr int TILE_A = BM * 128, TILE_BH = BN * 64;
+    constexpr int A0_OFF = 0, B0_OFF = TILE_A, B1_OFF = B0_OFF + TILE_BH, A1_OFF = B1_OFF + TILE_BH, A2_OFF = A1_OFF + TILE_A, B2_OFF = A2_OFF + TILE_A;
+    constexpr int RING_BYTES = B2_OFF + TILE_BH;
+    constexpr int EPI_ROWB = (EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64;
+    constexpr int EPI_BYTES = (NT / 64) * 32 * EPI_ROWB, EPI_OFF = A1_OFF;
+    static_assert(EPI_OFF + EPI_BYTES <= RING_BYTES, "epilogue staging inside A1 | A2 | B2");
+    constexpr bool LNF = EPI == 3 || EPI == 4, BIAS_LDS = EPI == 2 || EPI == 5;
+    constexpr int CVB = LNF ? 2 * BN * 4 : (BIAS_LDS ? BN * 2 : 0);
+    constexpr int LDS_BYTES = RING_BYTES + 2 * CVB;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    float* const cvec0 = (float*)(lds + RING_BYTES);
+    int cpar = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int col = lane & 31, hi = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const int grp = wid_s >> 2;
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w;
+    const T* zero = (const T*)g_zero_chunk;
+    // tile walk: as conv_ring_kernel
+    const int per_xcd = gridDim.x / 8;
+    const int xg_n = 8 / p.ngroups, tn_g = p.tiles_n / p.ngroups;
+    const int cgrp = (blockIdx.x % 8) / xg_n;
+    const long ntiles = p.nblocks / p.ngroups;
+    const long tile_first = (long)((blockIdx.x % 8) % xg_n) * per_xcd + blockIdx.x / 8;
+    const long tile_step = (long)xg_n * per_xcd;
+    auto tile_m0 = [&](long j) { return (long)((uint32_t)j / (uint32_t)tn_g) * BM; };
+    auto tile_n0 = [&](long j) { return (cgrp * tn_g + (int)((uint32_t)j % (uint32_t)tn_g)) * BN; };
+    const int K = p.Cin;
+    const int nst = K / 64, nh = 2 * nst;
+    const uint32_t lds_u32 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds);
+    auto a_off = [&](int s) { return s == 0 ? A0_OFF : (s == 1 ? A1_OFF : A2_OFF); };
+    auto b_off = [&](int s) { return s == 0 ? B0_OFF : (s == 1 ? B1_OFF : B2_OFF); };
+
+    // ---- producer: activations 8 chunks per 128-byte row (4 pieces per wave and stage), weights 4 chunks per 64-byte row
+    //      (2 pieces per wave and half stage, a third for waves 0 - 3 when the tile is 320 rows)
+    const int srowA = tid / 8, pdA = ((tid % 8) ^ ((srowA / 2) & 7)) * 8;
+    const int srowB = tid / 4, pdB = ((tid % 4) ^ ((srowB / 4) & 3)) * 8;
+    const T* aptr[4];
+    uint32_t amask = 0;
+    const T* bptr = wg;
+    const long bstride = 128L * K;
+    auto init_tile = [&](long tile) {
+        const long m0 = tile_m0(tile);
+        const int n0 = tile_n0(tile);
+        bptr = wg + (long)(n0 + srowB) * K + pdB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + srowA + i * 64;
+            const bool ok = m < p.M;
+            aptr[i] = ok ? xg + m * K + pdA : zero;
+            amask = ok ? (amask | (1u << i)) : (amask & ~(1u << i));
+        }
+    };
+    constexpr bool B3 = TN == 5;                  // rows 256 .. 319 of the weight tile
+    auto piece_a = [&](int slot, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        lds_dma16_asm(aptr[i], lds_u32 + (uint32_t)(a_off(slot) + wid_s * 1024 + i * 8192));
+        aptr[i] += ((amask >> i) & 1u) ? 64 : 0;
+    };
+    auto piece_b = [&](int slot, auto ic) {       // pieces 0, 1 every wave; piece 2 waves 0 - 3 (B3)
+        constexpr int i = decltype(ic)::value;
+        if (i < 2 || wid_s < 4) lds_dma16_asm(bptr + i * bstride, lds_u32 + (uint32_t)(b_off(slot) + wid_s * 1024 + i * 8192));
+    };
+    constexpr int NBP = B3 ? 3 : 2;               // piece slots of a half stage (the third is empty for waves 4 - 7)
+    auto issue_a = [&](int slot) { static_for<4>([&](auto ic) { piece_a(slot, ic); }); };
+    auto issue_b = [&](int slot) {
+        static_for<NBP>([&](auto ic) { piece_b(slot, ic); });
+        bptr += 32;
+    };
+    const int nb = B3 ? (wid_s < 4 ? 3 : 2) : 2;  // this wave's requests per half stage
+    auto wait_vm = [&](int n) {                   // at most n of this wave's youngest requests may still be in flight
+        switch (n) {
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    auto cv_fill = [&](long m0n, int n0n, int set) {      // as conv_ring_kernel's
+        constexpr int NL = LNF ? 2 * (BN / 4) : BN / 8;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_u32 + (uint32_t)(RING_BYTES + set * CVB + wid_s * 1024));
+        if (tid < NL) {
+            const void* src;
+            if constexpr (LNF) {
+                const int v = tid / (BN / 4), idx = (tid % (BN / 4)) * 4;
+                const float* c2 = p.ln_tab ? p.ln_tab + ((m0n / p.tab_div) % p.tab_mod) * (long)p.Cout : p.ln_c2;
+                src = (v ? c2 : p.ln_c1) + n0n + idx;
+            } else {
+                src = p.bias ? (const void*)((const T*)p.bias + n0n + tid * 8) : (const void*)zero;
+            }
+            lds_dma16_asm(src, dst);
+        }
+    };
+    // the first requests of a tile: A0, B0, B1 (everything the epilogue's staging does not cover)
+    auto issue_head = [&]() {
+        issue_b(0);
+        if (nh > 1) issue_b(1);
+        issue_a(0);
+    };
+
+    // fragment byte offsets
+    const int swzA = (col / 2) & 7, swzB = (col / 4) & 3;
+    int koffA[4], koffB[2];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) koffA[kc] = ((kc * 2 + hi) ^ swzA) * 16;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) koffB[k2] = ((k2 * 2 + hi) ^ swzB) * 16;
+    const int xrow = (wm * (TM * 32) + col) * 128, wrow = (wn * (TN * 32) + col) * 64;
+
+    long tile = tile_first;
+    if (tile >= ntiles) return;
+    init_tile(tile);
+    if constexpr (LNF || BIAS_LDS) cv_fill(tile_m0(tile), tile_n0(tile), 0);
+    issue_head();
+    bool prev_full = false;
+    for (;;) {
+        const long m0 = tile_m0(tile);
+        const int n0 = tile_n0(tile);
+        float* cvec = cvec0 + cpar * (CVB / 4);
+        f32x16 acc[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        constexpr int NTAIL = (EPI == 1 || EPI == 4) ? 6 : 16;
+        if (prev_full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NTAIL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (grp) {
+            // the trailing group skips one interval: what the leading group requests in its first R interval goes out here
+            if (nst > 1) issue_a(1);
+            if (nh > 2) issue_b(2);
+            if (nst > 2) issue_a(2);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        for (int st = 0; st < nst; ++st) {
+            const char* ax = lds + a_off(st % 3) + xrow;
+            const char* bw0 = lds + b_off((2 * st) % 3) + wrow;
+            const char* bw1 = lds + b_off((2 * st + 1) % 3) + wrow;
+            const bool rb2 = 2 * st + 2 < nh, ra2 = st + 2 < nst, rb3 = 2 * st + 3 < nh;       // requests of this stage's schedule
+            const bool rb4 = 2 * st + 4 < nh, ra3 = st + 3 < nst;                               // (trailing group: next stage's first)
+            // younger requests that may stay in flight at the two waits (see the header)
+            const int c0 = ((st == 0 && nst > 1) ? 4 : 0) + (rb2 ? nb : 0) + (ra2 ? 4 : 0);
+            const int c1 = (ra2 ? 4 : 0) + (rb3 ? nb : 0);
+            u32x4 xf[2][TM], wf[2][TN];
+            // ---- R0
+            if (!grp) {
+                if (st == 0 && nst > 1) issue_a(1);
+                if (rb2) issue_b((2 * st + 2) % 3);
+                if (ra2) issue_a((st + 2) % 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(ax + koffA[kc] + b * (32 * 128));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(bw0 + koffB[kc] + a * (32 * 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp) wait_vm(c0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- C0
+            __builtin_amdgcn_s_setprio(1);
+            static_for<2 * TN * TM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                if constexpr (m % 4 == 3 && m / 4 < NBP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (grp && rb3) piece_b((2 * st + 3) % 3, std::integral_constant<int, m / 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if (grp && rb3) bptr += 32;
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!grp) wait_vm(c0);
+            asm volatile("s_barrier" ::: "memory");
+            // ---- R1
+            if (!grp && rb3) issue_b((2 * st + 3) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) xf[kc][b] = *(const u32x4*)(ax + koffA[2 + kc] + b * (32 * 128));
+#pragma unroll
+                for (int a = 0; a < TN; ++a) wf[kc][a] = *(const u32x4*)(bw1 + koffB[kc] + a * (32 * 64));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp && rb2) wait_vm(c1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- C1
+            __builtin_amdgcn_s_setprio(1);
+            static_for<2 * TN * TM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, kc = m / (TN * TM), a = (m / TM) % TN, b = m % TM;
+                acc[a][b] = Elem<T>::mfma32(__builtin_bit_cast(uint4, wf[kc][a]), __builtin_bit_cast(uint4, xf[kc][b]), acc[a][b]);
+                if constexpr (m % 2 == 1 && m / 2 < NBP + 4) {
+                    constexpr int j = m / 2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (j < NBP) {
+                        if (grp && rb4) piece_b((2 * st + 4) % 3, std::integral_constant<int, (j < NBP ? j : 0)>{});
+                    } else {
+                        if (grp && ra3) piece_a((st + 3) % 3, std::integral_constant<int, (j >= NBP ? j - NBP : 0)>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if (grp && rb4) bptr += 32;
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!grp && rb2) wait_vm(c1);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        if (!grp) asm volatile("s_barrier" ::: "memory");
+        float ln_pre[2 * TM];
+        if constexpr (EPI == 3 || EPI == 4) {
+            float mus[TM], rstds[TM];
+            epi_ln_row_stats<TM>(p, m0, wid_s / WN, lane & 31, mus, rstds);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                ln_pre[b] = mus[b];
+                ln_pre[TM + b] = rstds[b];
+            }
+        }
+        asm volatile("s_barrier" ::: "memory");          // every wave is done reading operand buffers
+        const long next = tile + tile_step;
+        if (next < ntiles) {
+            init_tile(next);
+            if constexpr (LNF || BIAS_LDS) cv_fill(tile_m0(next), tile_n0(next), cpar ^ 1);
+            issue_head();
+        }
+        int lane_e = lane, wid_e = wid_s;
+        asm volatile("" : "+v"(lane_e), "+s"(wid_e));
+        tile_epilogue<T, NT, TM, TN, EPI, true, false, GNS, WN, RESM>(p, acc, lds + EPI_OFF, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, cvec, BN, (EPI == 3 || EPI == 4) ? ln_pre : nullptr);
+        if (next >= ntiles) break;
+        cpar ^= 1;
+        prev_full = m0 + BM <= p.M;
+        tile = next;
+    }
+}
+
 // ---- 3x3 convolution from a halo'd pixel patch ----------------------------------------------------------------------
 // The kernels above stream one shifted copy of the pixel tile per tap: nine LDS-DMA loads of every activation, 9x the
 // input tensor through the L2 / fabric (profiles: fetch / input = 8.9 .. 14), and the CU's global -> LDS path (~21 B/clk)
@@ -1887,6 +2159,23 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     // the default loop's kernels exist per residual mode of the epilogue (tile_epilogue, RESM): present / absent are different code
     auto launch_stag = [&](auto gns_c) {
         constexpr bool G = decltype(gns_c)::value;
+#ifdef IM360_ABLATE
+        // measured and not shipped (profiles/r04_gemm_a3_ab.log): identical bits on every shape and epilogue at the first run, but
+        // 0.85 - 0.97 x the staggered loop's speed (only the level-0 GEGLU ties): with the weight tile in 64-byte row segments the
+        // L2 -> LDS path carries 2170 clk of transfers per stage instead of 1385, and that path's throughput -- not only the latency
+        // of the activation rows -- is what the K loop runs against
+        if constexpr (LINEAR && EPI != 3) {             // (EPI 3's two sets of c1 | c2 do not fit next to the A3 kernel's 156 KB)
+            if (variant == 10) {                        // two activation stages in flight (gemm_a3_kernel)
+                if constexpr (EPI == 1 || EPI == 4) {
+                    hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 0>), dim3(grid), dim3(512), 0, stream, p);
+                } else {
+                    if (p.res) hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 1>), dim3(grid), dim3(512), 0, stream, p);
+                    else hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 2>), dim3(grid), dim3(512), 0, stream, p);
+                }
+                return;
+            }
+        }
+#endif
         if constexpr (EPI == 1 || EPI == 4) {
             hipLaunchKernelGGL((conv_ring_kernel<T, TN, EPI, LINEAR, true, 3, G, 0>), dim3(grid), dim3(512), 0, stream, p);
         } else if constexpr (EPI == 3) {
@@ -2237,7 +2526,7 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     ProfScope prof(PROF_GEMM, stream);
     const int kr = knob(KNOB_CONV_RING);
     const int v = kr == 5 ? 1 : (kr == 7 ? 6 : kr);
-    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, v == 8 ? 8 : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, v == 8 ? 8 : 1);
+    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, (v == 8 || v == 10) ? v : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, (v == 8 || v == 10) ? v : 1);
     return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);
 }
 
@@ -2268,7 +2557,7 @@ extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const vo
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    const int v6 = knob(KNOB_CONV_RING) == 8 ? 8 : 1;
+    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 5, 3, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 5, 3, true>(p, (hipStream_t)stream, v6);
 }
 
@@ -2293,7 +2582,7 @@ extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const 
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    const int v6 = knob(KNOB_CONV_RING) == 8 ? 8 : 1;
+    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);
 }
 

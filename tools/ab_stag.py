@@ -12,7 +12,7 @@ from imagine360_amd import kernels as K  # noqa: E402
 from tools.bench_kernels import timeit, rn  # noqa: E402
 
 iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
-VARIANTS = [1, 6]
+VARIANTS = [1, 10]          # 1 = default (staggered 64-channel stages), 10 = two activation stages in flight (gemm_a3_kernel); 8 = round 3 ring
 
 
 def ab(name, fn, fl):
