@@ -210,6 +210,9 @@ def main(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--warp-streams", type=int, default=1, help="with --dual-stream: the two directions of every WarpAttn on the two streams too")
     ap.add_argument("--dual-stream", type=int, default=1, help="1 (default): the panorama branch between WarpAttn calls on a side stream (two parallel branches in the hipGraph); 0: one stream")
+    ap.add_argument("--dual-stream-shard", type=int, default=0,
+                    help="with --parallelism frames: 1 = a second communicator for the panorama UNet's all-to-alls so that the panorama "
+                         "branch keeps its side stream under the shard (opt-in: never measured on more than one GPU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: PLUMBING CHECK on CPU tensors (tests/test_dist_cpu.py): the rank bookkeeping, sharding, collectives and the JSON "
                          "line of this script with whatever `imagine360_amd.kernels` the caller installed; never a benchmark number")
@@ -272,15 +275,21 @@ def main(argv=None):
         from imagine360_amd.dist import FrameShard, exchange_cfg_halves, shard_mv_inputs
         torch.manual_seed(1234)
         random.seed(1234)
+        pano_shard = None
         if mode == "frames":
-            shard = FrameShard(frames)
+            if args.dual_stream_shard:
+                from imagine360_amd.dist import frame_shard_pair
+                shard, pano_shard = frame_shard_pair(frames)
+                mv.dual_stream_shard = True
+            else:
+                shard = FrameShard(frames)
         else:
             from imagine360_amd.dist import cfg_frame_layout, cfg_half_inputs
             my_half, shard, pair = cfg_frame_layout(frames)
             inp = cfg_half_inputs(inp, my_half)
             mv._ip_noise_half = (my_half, 2)
         inp = shard_mv_inputs(inp, shard)
-        mv.set_frame_shard(shard)
+        mv.set_frame_shard(shard, pano_shard)
     sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
     nsteps_total = 25
     sch.set_timesteps(nsteps_total)
@@ -437,7 +446,7 @@ def main(argv=None):
             "scaling": "weak" if mode == "samples" else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "tuned_gemm_table": tuned, "tuned_gemm_table_status": (tuning.STATUS if not args.no_tuned_gemms else {"applied": False, "reason": "--no-tuned-gemms"}),
-            "launch": ("eager, one stream" if graphed is None else "hipGraph replay (one captured step)") + (", panorama branch on a side stream between the WarpAttn calls" if mv.dual_stream and shard is None and graphed is not None else ""),
+            "launch": ("eager, one stream" if graphed is None else "hipGraph replay (one captured step)") + (", panorama branch on a side stream between the WarpAttn calls" if mv.dual_stream and (shard is None or (mv.dual_stream_shard and mv._shard_two_comms)) and graphed is not None else ""),
             "config": {"workload": w["desc"],
                        "parallelism": {"samples": f"sample-parallel x{world}" if world > 1 else "single GPU",
                                        "frames": f"frame-chunk sharding x{world} ({frames // max(world, 1)} frames per GPU)",

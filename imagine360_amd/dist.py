@@ -99,6 +99,16 @@ def cfg_frame_layout(frames, world=None, rank=None):
     return my_half, FrameShard(frames, group=groups[my_half], rank=rank % half, world=half), pairs[rank % half]
 
 
+def frame_shard_pair(total_frames, group=None):
+    """(shard, pano_shard): two FrameShards over the ranks of ``group`` -- the second on a NEW process group of the same ranks
+    (a second RCCL communicator) for the panorama UNet (``MultiViewBaseModel.set_frame_shard(shard, pano_shard)``).  Collective:
+    every rank of ``group`` has to call it (``dist.new_group``)."""
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+    second = dist.new_group(ranks=ranks)
+    world, rank = len(ranks), ranks.index(dist.get_rank())
+    return FrameShard(total_frames, group=group, rank=rank, world=world), FrameShard(total_frames, group=second, rank=rank, world=world)
+
+
 class FrameShard:
     """Contiguous frame chunks across the ranks of ``group`` (frames % world == 0)."""
 

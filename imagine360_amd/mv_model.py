@@ -168,7 +168,10 @@ class MultiViewBaseModel(nn.Module):
         self._ip_noise_half = None      # (half index, 2) when this rank runs one CFG half (BASELINE config 5 layout)
         self.dual_stream = True         # the panorama branch's segments between WarpAttn calls run on a side stream (GPU, unsharded)
         self._sharded = False
+        self._shard_two_comms = False
         self.dual_stream_eager = False  # (tests / A-B only) use the side stream for eagerly issued steps too; see _two_streams
+        self.dual_stream_shard = False  # opt-in: keep the side stream under a frame shard WHEN the panorama UNet has its own communicator
+                                        # (set_frame_shard(shard, pano_shard)); never measured on more than one GPU, off by default
         self.warp_streams = True        # with dual_stream: the two directions of every WarpAttn on the two streams as well
         self._streams = {}
 
@@ -201,7 +204,7 @@ class MultiViewBaseModel(nn.Module):
         bench.py's parity_check and tests/test_model_gpu.py.  Eagerly issued steps stay on one stream unless ``dual_stream_eager``
         is set: round 4 found the eager two-stream step at cfg2 size intermittently not bit-identical (one bench run in two),
         i.e. a lifetime hazard across the two allocator pools that capture does not have; eager issue is host-bound anyway."""
-        if not self.dual_stream or self._sharded:
+        if not self.dual_stream or (self._sharded and not (self.dual_stream_shard and self._shard_two_comms)):
             return False
         return self.dual_stream_eager or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
@@ -244,14 +247,20 @@ class MultiViewBaseModel(nn.Module):
             hit = cams
         return hit
 
-    def set_frame_shard(self, shard):
+    def set_frame_shard(self, shard, pano_shard=None):
         """Frame-chunk sharding (imagine360_amd.dist.FrameShard): the model is fed this rank's frames and every
-        motion-module attention exchanges tokens with one all-to-all each way."""
+        motion-module attention exchanges tokens with one all-to-all each way.  ``pano_shard``: a second FrameShard over the
+        same ranks on ITS OWN process group (``dist.frame_shard_pair``) for the panorama UNet's motion modules -- collectives of
+        one communicator have to stay on one stream, so only with two communicators may the panorama branch keep its side
+        stream under a shard (``dual_stream_shard``, opt-in)."""
         from .unet3d import VersatileAttention
         self._sharded = shard is not None       # (collectives of one communicator stay on one stream: no side stream then)
+        self._shard_two_comms = (shard is not None and pano_shard is not None and pano_shard.group is not None
+                                 and pano_shard.group is not shard.group)
+        pano_mods = {id(m) for m in self.pano_unet.modules()}
         for mod in self.modules():
             if isinstance(mod, VersatileAttention):
-                mod.frame_shard = shard
+                mod.frame_shard = (pano_shard if (pano_shard is not None and shard is not None and id(mod) in pano_mods) else shard)
 
     def _ip_noise(self, like):
         half = self._ip_noise_half

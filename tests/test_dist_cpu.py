@@ -147,6 +147,44 @@ def _mv_sharded_job(rank, world):
             list(pano_loc.shape), list(pers_loc.shape)]
 
 
+def _mv_two_communicators_job(rank, world):
+    """The panorama UNet's all-to-alls on a second process group (dist.frame_shard_pair; what `dual_stream_shard` needs on a GPU):
+    same result as with one communicator, and the motion modules of the two UNets really hold different groups."""
+    import random
+    import _emu_kernels as E
+    from imagine360_amd import configs, synthetic as S
+    from imagine360_amd.dist import FrameShard, frame_shard_pair, shard_mv_inputs
+    from imagine360_amd.unet3d import VersatileAttention
+    mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True)
+    mv.noise_on_host = True
+    frames = 4
+    inp = S.mv_inputs(frames=frames, pano_hw=(32, 64), pers_hw=(16, 16), seed=5, sam_frames=16)
+    cams = S.icosahedron_cameras(90, 128)
+    kw = dict(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True)
+    outs = []
+    with E.patched_kernels():
+        sh1 = FrameShard(frames)
+        sh, psh = frame_shard_pair(frames)
+        for shards in ((sh1, None), (sh, psh)):
+            mv.set_frame_shard(*shards)
+            torch.manual_seed(3)
+            random.seed(3)
+            outs.append(mv(**kw, **shard_mv_inputs(inp, shards[0])))
+            two = mv._shard_two_comms
+            groups = ({id(m.frame_shard.group) for m in mv.pano_unet.modules() if isinstance(m, VersatileAttention)},
+                      {id(m.frame_shard.group) for m in mv.unet.modules() if isinstance(m, VersatileAttention)})
+            mv.set_frame_shard(None)
+    same = all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    return [same, two, len(groups[0]) == 1 and len(groups[1]) == 1 and groups[0] != groups[1], mv._sharded, mv._shard_two_comms]
+
+
+def test_panorama_branch_on_its_own_communicator_matches_one_communicator():
+    res = _run(_mv_two_communicators_job)
+    assert len(res) == 2
+    for same, two, distinct, still_sharded, still_two in res.values():
+        assert same and two and distinct and not still_sharded and not still_two
+
+
 def test_frame_sharded_mv_forward_matches_unsharded():
     out = _run(_mv_sharded_job)
     for r in range(2):
