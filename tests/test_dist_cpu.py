@@ -285,7 +285,7 @@ def test_frame_sharded_pipeline_call_matches_unsharded():
 
 
 # ------------------------------------------------------------------ bench.py's own multi-rank plumbing
-def _bench_main(rank, world, mode):
+def _bench_main(rank, world, mode, extra=()):
     import sys
     import _emu_kernels as E
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -295,7 +295,7 @@ def _bench_main(rank, world, mode):
     os.environ["LOCAL_RANK"] = str(rank)
     with E.patched_kernels():
         return bench.main(["--gpus", str(world), "--backend", "gloo", "--steps", "1", "--warmup", "1", "--workload", "cfg1",
-                           "--width-div", "10", "--parallelism", mode])
+                           "--width-div", "10", "--parallelism", mode, *extra])
 
 
 def _bench_samples(rank, world):
@@ -303,7 +303,8 @@ def _bench_samples(rank, world):
 
 
 def _bench_frames(rank, world):
-    return _bench_main(rank, world, "frames")
+    # (with the opt-in second communicator for the panorama UNet: the flag's plumbing in bench.py; cfgxframes covers the default)
+    return _bench_main(rank, world, "frames", ("--dual-stream-shard", "1"))
 
 
 def _bench_cfgxframes(rank, world):
