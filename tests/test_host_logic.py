@@ -434,3 +434,40 @@ def test_dropin_preprocess_aliases_are_opt_in():
     assert extra["animatediff.utils.video_mask"]["get_anchor_target"] is preprocess.get_anchor_target
     assert extra["src.modules.utils"]["get_maxrec_cord"] is preprocess.get_maxrec_cord
     assert not any(k.startswith("src.utils.pano_utils") or k == "animatediff.utils.video_mask" for k in dropin._ALIASES)
+
+
+def test_measurement_tools_parse_what_they_claim(tmp_path):
+    """The two text tools the round-4 evidence rests on, on tiny synthetic inputs: tools/kernel_event_map.py (instruction-order map
+    of a kernel from device assembly: the check that no scratch reload sits inside a K loop) and tools/trace_by_shape.py (a
+    rocprofv3 kernel trace grouped by kernel and grid, tail of N steps)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_event_map", os.path.join(root, "tools", "kernel_event_map.py"))
+    kem = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kem)
+    body = ["\tglobal_load_lds_dwordx4 v[0:1], off", "\ts_waitcnt vmcnt(16)", "\ts_barrier", "\tds_read_b128 v[4:7], v2", "\tds_read_b128 v[8:11], v2",
+            "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[4:7], v[8:11], v[0:15]", "\tscratch_load_dwordx2 v[2:3], off, off", "\ts_waitcnt vmcnt(0)",
+            "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[4:7], v[8:11], v[0:15]", "\tglobal_store_dwordx4 v[0:1], v[4:7], off"]
+    assert kem.event_map(body) == "G v16  | d2 M L v0  M W"
+    # trace_by_shape: two steps, each ending with two cfg_ddim launches; the tail of ONE step must hold only the second step's rows
+    hdr = "Kind,Agent_Id,Queue_Id,Stream_Id,Thread_Id,Dispatch_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Workgroup_Size_X,Workgroup_Size_Y,Workgroup_Size_Z,Grid_Size_X,Grid_Size_Y,Grid_Size_Z"
+    rows, t = [], 0
+
+    def launch(name, dur, grid, wg):
+        nonlocal t
+        rows.append(f"KERNEL_DISPATCH,1,1,1,1,{len(rows)},1,\"{name}\",1,{t},{t + dur},0,0,64,0,32,{wg},1,1,{grid * wg},1,1")
+        t += dur + 10
+
+    for step in range(2):
+        launch("_ZN5im36016conv_ring_kernelIDF16bLi5ELi2ELb1ELb1ELi3ELb0ELi2EEEvNS_10ConvParamsE", 1000 * (step + 1), 256, 512)
+        launch("_ZN5im36017gn_apply_kernelIDF16bEEvPKT_PKfS5_PS1_iiiiiiii", 100, 2560, 256)
+        launch("_ZN5im36015cfg_ddim_kernelIDF16bEEvPKT_S3_S3_PS1_lfffPKf", 5, 64, 256)
+        launch("_ZN5im36015cfg_ddim_kernelIDF16bEEvPKT_S3_S3_PS1_lfffPKf", 5, 64, 256)
+    f = tmp_path / "t_kernel_trace.csv"
+    f.write_text(hdr + "\n" + "\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_by_shape.py"), str(f), "--steps", "1"], capture_output=True, text=True, check=True).stdout
+    assert "# 4 dispatches over 1 step(s)" in out
+    ring = [ln for ln in out.splitlines() if "conv_ring_kernel" in ln and "grid=" in ln]
+    assert len(ring) == 1 and ring[0].split()[0] == "0.002" and "grid=(256, 1, 1) x 512" in ring[0], ring
