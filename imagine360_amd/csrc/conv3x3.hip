@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-if (ABL & 4) {
+                if (ABL & 4) {             // (ablation build: constant fragments instead of the LDS reads)
 #pragma unroll
                     for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
@@ -1327,7 +1327,7 @@ if (ABL & 4) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_barrier" ::: "memory");
                 // ---- R(st, 1)
-if (!(ABL & 4))
+                if (!(ABL & 4))
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
 #pragma unroll
