@@ -925,11 +925,11 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 template <typename T, int TN, int EPI, bool LINEAR, bool ASM_DMA, int MODE, bool GNS = false, int RESM = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void conv_ring_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2;
-    constexpr bool STAG64 = (MODE & 15) == 3;
+    constexpr bool STAG64 = (MODE & 15) == 3;            // 64-channel stages in two buffers, staggered wave groups (below)
     constexpr bool PLAIN64 = (MODE & 15) == 4;           // 64-channel stages in two buffers, conv_igemm_kernel's loop (one barrier per stage) in this persistent shell
     constexpr bool BK64 = STAG64 || PLAIN64;
     constexpr int ABL = (MODE >> 4) & 7;                 // ablation builds of the loop (tools/ab_stag.py --ablate): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
-    constexpr bool CMK = !LINEAR && (MODE & 128) != 0;   // 3 x 3 convolution with the taps innermost (conv_igemm_kernel's CM producer: same K order, same bits)                   // 64-channel stages in two buffers, staggered wave groups (below)
+    constexpr bool CMK = !LINEAR && (MODE & 128) != 0;   // 3 x 3 convolution with the taps innermost (conv_igemm_kernel's CM producer: same K order, same bits)
     constexpr int BM = 256, BN = WN * TN * 32, BK = BK64 ? 64 : 32;
     constexpr int CPR = BK / 8, ROWB = BK * 2, RPB = 256 / ROWB;      // 4 chunks per 64-byte row, 4 rows per bank row (8 / 2 at 64 channels)
     constexpr int KC = BK / 16;
