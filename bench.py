@@ -213,6 +213,10 @@ def main(argv=None):
     ap.add_argument("--dual-stream-shard", type=int, default=0,
                     help="with --parallelism frames: 1 = a second communicator for the panorama UNet's all-to-alls so that the panorama "
                          "branch keeps its side stream under the shard (opt-in: never measured on more than one GPU)")
+    ap.add_argument("--shard-boundary", default="module", choices=["module", "attention"],
+                    help="frame modes: where the motion modules exchange tokens -- module (default: one C-wide all-to-all behind the "
+                         "module's GroupNorm and one in front of its residual add, 2 C per token and module) or attention (round 3: "
+                         "3 C out + C back around every temporal attention, 8 C per module)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: PLUMBING CHECK on CPU tensors (tests/test_dist_cpu.py): the rank bookkeeping, sharding, collectives and the JSON "
                          "line of this script with whatever `imagine360_amd.kernels` the caller installed; never a benchmark number")
@@ -279,13 +283,13 @@ def main(argv=None):
         if mode == "frames":
             if args.dual_stream_shard:
                 from imagine360_amd.dist import frame_shard_pair
-                shard, pano_shard = frame_shard_pair(frames)
+                shard, pano_shard = frame_shard_pair(frames, boundary=args.shard_boundary)
                 mv.dual_stream_shard = True
             else:
-                shard = FrameShard(frames)
+                shard = FrameShard(frames, boundary=args.shard_boundary)
         else:
             from imagine360_amd.dist import cfg_frame_layout, cfg_half_inputs
-            my_half, shard, pair = cfg_frame_layout(frames)
+            my_half, shard, pair = cfg_frame_layout(frames, boundary=args.shard_boundary)
             inp = cfg_half_inputs(inp, my_half)
             mv._ip_noise_half = (my_half, 2)
         inp = shard_mv_inputs(inp, shard)
@@ -453,6 +457,12 @@ def main(argv=None):
                                        "cfgxframes": f"CFG halves x frame chunks (2 x {world // 2})"}[mode],
                        "width_div": args.width_div, "ddim_steps_schedule": nsteps_total, "guidance": guidance,
                        "tflop_per_step": total / 1e12, "outputs_finite": finite},
+            **({"shard_boundary": shard.boundary,
+                "dual_stream_shard": {"enabled": bool(mv.dual_stream_shard and mv._shard_two_comms),
+                                      "validated_on_rccl": False,
+                                      "note": "two communicators progressing concurrently on two streams inside one captured graph have only "
+                                              "run as gloo plumbing (tests/test_dist_cpu.py); a number measured with it is UNVALIDATED"}}
+               if shard is not None else {}),
             "parity_check": parity_check,
             "whole_step_tflops": total / 1e12 * steps_per_s / world,          # per GPU
             "whole_step_frac_of_mfma_peak": total / 1e12 * steps_per_s / world / MFMA_PEAK_TFLOPS,

@@ -13,7 +13,7 @@
 
 static thread_local char g_err[512] = "";
 
-extern "C" void im360_set_error(const char* fmt, ...) {
+extern "C" __attribute__((visibility("hidden"))) void im360_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -22,7 +22,9 @@ extern "C" void im360_set_error(const char* fmt, ...) {
 
 extern "C" const char* im360_last_error(void) { return g_err; }
 
-extern "C" int im360_abi_version(void) { return 1; }
+// 2 (round 5): im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer, im360_linear_ln_fwd's table rows include c2
+// (round 4 changed both without bumping the number; callers built against version 1 must not load this library)
+extern "C" int im360_abi_version(void) { return 2; }
 
 // bit 0: built with -DIM360_ABLATE (`make ablate`): the rejected A/B variants and the ablation kernels are in the library
 extern "C" int im360_build_flags(void) {

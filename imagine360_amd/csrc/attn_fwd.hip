@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
 #pragma unroll
             for (int kb = K0; kb < K1; ++kb) {
                 f32x16& sv = s[qb][kb];
-                if (HAS_BIAS && !BF) {
+                if constexpr (HAS_BIAS && !BF) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint2 w = bw[qb][QK_ALL ? kb : 0][g];

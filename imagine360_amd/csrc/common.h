@@ -217,7 +217,8 @@ __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * 
 #define IM360_ERR_UNSUPPORTED (-2)
 #define IM360_ERR_LAUNCH (-3)
 
-extern "C" void im360_set_error(const char* fmt, ...);
+// library-internal (hidden: not part of the C ABI; callers read the message through im360_last_error)
+extern "C" __attribute__((visibility("hidden"))) void im360_set_error(const char* fmt, ...);
 #define IM360_CHECK_ARG(cond, ...)            \
     do {                                       \
         if (!(cond)) {                         \

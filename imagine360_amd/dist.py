@@ -9,8 +9,11 @@ reference's arithmetic is independent:
   * frames (BASELINE configs 4/5): every op is per (batch, frame) image -- conv, GroupNorm, spatial and
     cross-view attention -- except the motion modules' attention over the frame axis.  ``FrameShard``
     gives each rank a contiguous chunk of frames and turns frame-sharded tokens into pixel-sharded tokens
-    (and back) with one all-to-all per temporal attention, Ulysses style; xGMI is point-to-point, so an
-    all-to-all of activation slabs uses all 7 links at once where a ring would be bound by one.
+    (and back) with one all-to-all each way PER MOTION MODULE (round 5: everything between the module's
+    GroupNorm and its residual add is per pixel over frames or per token, so the whole temporal transformer
+    runs pixel-sharded -- 2 C per token and module on the wire; ``boundary="attention"`` keeps round 3's
+    exchange around every attention, 8 C); xGMI is point-to-point, so an all-to-all of activation slabs
+    uses all 7 links at once where a ring would be bound by one.
 
 ``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code runs on "gloo" for the CPU tests.
 """
@@ -84,7 +87,7 @@ def exchange_cfg_halves(pred, pair_group):
     return torch.cat(parts)
 
 
-def cfg_frame_layout(frames, world=None, rank=None):
+def cfg_frame_layout(frames, world=None, rank=None, boundary="module"):
     """Rank layout of the CFG x frames decomposition: ranks [0, world/2) take the unconditional half, the rest the text
     half; inside a half the frames are sharded.  Returns (half index, FrameShard of the half, pair group).  Every rank
     must call this (it creates process groups collectively)."""
@@ -96,23 +99,30 @@ def cfg_frame_layout(frames, world=None, rank=None):
     groups = [dist.new_group(list(range(h * half, (h + 1) * half))) for h in range(2)]
     pairs = [dist.new_group([r, r + half]) for r in range(half)]
     my_half = rank // half
-    return my_half, FrameShard(frames, group=groups[my_half], rank=rank % half, world=half), pairs[rank % half]
+    return my_half, FrameShard(frames, group=groups[my_half], rank=rank % half, world=half, boundary=boundary), pairs[rank % half]
 
 
-def frame_shard_pair(total_frames, group=None):
+def frame_shard_pair(total_frames, group=None, boundary="module"):
     """(shard, pano_shard): two FrameShards over the ranks of ``group`` -- the second on a NEW process group of the same ranks
     (a second RCCL communicator) for the panorama UNet (``MultiViewBaseModel.set_frame_shard(shard, pano_shard)``).  Collective:
     every rank of ``group`` has to call it (``dist.new_group``)."""
     ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
     second = dist.new_group(ranks=ranks)
     world, rank = len(ranks), ranks.index(dist.get_rank())
-    return FrameShard(total_frames, group=group, rank=rank, world=world), FrameShard(total_frames, group=second, rank=rank, world=world)
+    return (FrameShard(total_frames, group=group, rank=rank, world=world, boundary=boundary),
+            FrameShard(total_frames, group=second, rank=rank, world=world, boundary=boundary))
 
 
 class FrameShard:
-    """Contiguous frame chunks across the ranks of ``group`` (frames % world == 0)."""
+    """Contiguous frame chunks across the ranks of ``group`` (frames % world == 0).  ``boundary``: where the motion
+    modules exchange tokens -- "module" (default: one all-to-all behind the module's GroupNorm, one in front of its
+    residual add; TemporalTransformer3DModel._forward_pixel_sharded) or "attention" (around every temporal attention;
+    VersatileAttention.forward)."""
 
-    def __init__(self, total_frames, group=None, rank=None, world=None):
+    def __init__(self, total_frames, group=None, rank=None, world=None, boundary="module"):
+        if boundary not in ("module", "attention"):
+            raise ValueError(f"FrameShard boundary {boundary!r}: 'module' or 'attention'")
+        self.boundary = boundary
         self.group = group
         self.world = dist.get_world_size(group) if world is None else world
         self.rank = dist.get_rank(group) if rank is None else rank
@@ -135,7 +145,7 @@ class FrameShard:
         return torch.cat(parts, dim=dim)
 
     # ---- frame-sharded tokens [B, Fl, P, C]  <->  pixel-sharded tokens of ALL frames, layout [F_total, B, PP, C] ----------
-    # One all-to-all each way per motion-module attention.  The buffers are pre-sized and cached per shape (stable
+    # One all-to-all each way per motion module (boundary "module") or per motion-module attention ("attention").  The buffers are pre-sized and cached per shape (stable
     # addresses: with RCCL the exchange can be captured in a hipGraph); pack / unpack are ONE kernel each
     # (kernels.shard_pack) and the receive buffer is consumed in place by the temporal-attention kernel through its frame /
     # batch strides (``kernels.temporal_attention(..., frame_major=True)``), which writes the return trip's send buffer.

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
+ABI_VERSION = 2          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
+
 PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
 
 
@@ -97,6 +99,11 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        have = L.im360_abi_version()
+        if have != ABI_VERSION:
+            # (version 1 -> 2 added a trailing pointer to two entry points; a stale library would read garbage for it)
+            raise RuntimeError(f"{_LIB_PATH} reports C-ABI version {have}, this binding is written for version {ABI_VERSION}: "
+                               "rebuild it with `make -C imagine360_amd/csrc`")
         _lib = L
     return _lib
 

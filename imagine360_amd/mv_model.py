@@ -86,7 +86,7 @@ class WarpAttn(nn.Module):
                 publish_to_all_streams(self._geom[key][:4])
         return self._geom[key]
 
-    def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None, side=None):
+    def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None, side=None, diag=(False, False)):
         """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes.  ``sel``: device int32
         scalar holding the normal (0) / antipodal (1) mask choice; then both variants are handed to the kernel and
         the choice is made on the device, which keeps the whole denoising step replayable from a hipGraph."""
@@ -126,11 +126,22 @@ class WarpAttn(nn.Module):
             # once both projections exist the two directions are independent: the panorama's (the smaller grids) on the side
             # stream.  eq / qkv_e / qkv_p were allocated on this stream and stay referenced by this frame until after the join.
             main = torch.cuda.current_stream()
+            eager = not torch.cuda.is_current_stream_capturing()
+            if eager and diag[1]:
+                torch.cuda.synchronize()
             side.wait_stream(main)
+            if eager and diag[0]:
+                for tns in (eq, qkv_e, qkv_p, b_e2p, alt_e2p):          # main-stream tensors the side stream reads
+                    if torch.is_tensor(tns):
+                        tns.record_stream(side)
             with torch.cuda.stream(side):
                 eq_out = equi_chain(eq)
             pr = pers_chain(pr)
             main.wait_stream(side)
+            if eager and diag[0]:
+                eq_out.record_stream(main)                              # side-stream tensor the main stream reads from here on
+            if eager and diag[1]:
+                torch.cuda.synchronize()
             eq = eq_out
         else:
             eq = equi_chain(eq)
@@ -174,6 +185,9 @@ class MultiViewBaseModel(nn.Module):
                                         # (set_frame_shard(shard, pano_shard)); never measured on more than one GPU, off by default
         self.warp_streams = True        # with dual_stream: the two directions of every WarpAttn on the two streams as well
         self._streams = {}
+        self.tap_fn = None              # (diagnostics, tools/dual_stream_race.py) taps / debug_taps keep tap_fn(tensor) instead of the tensor
+        self.record_streams = False     # (diagnostics, eager issue only) Tensor.record_stream on everything that crosses the two streams
+        self.sync_joins = False         # (diagnostics, eager issue only) device synchronise at every fork / join of the side stream
 
     def _run_pair(self, pers_fn, pano_fn, inputs):
         """One segment of each branch between two WarpAttn calls (they share nothing but read-only conditioning).  With
@@ -191,11 +205,20 @@ class MultiViewBaseModel(nn.Module):
             return
         main = torch.cuda.current_stream()
         side = self._stream(0, x0.device)
+        eager = not torch.cuda.is_current_stream_capturing()
+        if eager and self.sync_joins:
+            torch.cuda.synchronize()
         side.wait_stream(main)
+        if eager and self.record_streams:
+            for t in inputs:                       # main-stream tensors the side stream reads
+                if torch.is_tensor(t):
+                    t.record_stream(side)
         with torch.cuda.stream(side):
             pano_fn()
         pers_fn()
         main.wait_stream(side)
+        if eager and self.sync_joins:
+            torch.cuda.synchronize()
         del inputs
 
     def _two_streams(self):
@@ -253,14 +276,17 @@ class MultiViewBaseModel(nn.Module):
         same ranks on ITS OWN process group (``dist.frame_shard_pair``) for the panorama UNet's motion modules -- collectives of
         one communicator have to stay on one stream, so only with two communicators may the panorama branch keep its side
         stream under a shard (``dual_stream_shard``, opt-in)."""
-        from .unet3d import VersatileAttention
+        from .unet3d import TemporalTransformer3DModel, VersatileAttention
         self._sharded = shard is not None       # (collectives of one communicator stay on one stream: no side stream then)
         self._shard_two_comms = (shard is not None and pano_shard is not None and pano_shard.group is not None
                                  and pano_shard.group is not shard.group)
         pano_mods = {id(m) for m in self.pano_unet.modules()}
         for mod in self.modules():
-            if isinstance(mod, VersatileAttention):
-                mod.frame_shard = (pano_shard if (pano_shard is not None and shard is not None and id(mod) in pano_mods) else shard)
+            if isinstance(mod, (VersatileAttention, TemporalTransformer3DModel)):
+                sh = (pano_shard if (pano_shard is not None and shard is not None and id(mod) in pano_mods) else shard)
+                # the exchange sits at the module boundary (default) or around every attention: exactly one of the two holds the shard
+                at_module = sh is not None and sh.boundary == "module"
+                mod.frame_shard = sh if at_module == isinstance(mod, TemporalTransformer3DModel) else None
 
     def _ip_noise(self, like):
         half = self._ip_noise_half
@@ -294,10 +320,13 @@ class MultiViewBaseModel(nn.Module):
 
         warp_side = self._stream(0, x.device) if (self._two_streams() and self.warp_streams and x.is_cuda) else None
 
+        tap_fn = self.tap_fn if self.tap_fn is not None else (lambda t: t)
+        diag = (self.record_streams, self.sync_joins)
+
         def warp(blk, name, a, e):
-            a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]], side=warp_side)
+            a, e = blk.forward_cl(a, e, cams, f, sel=coins[order[name]], side=warp_side, diag=diag)
             if taps is not None:
-                taps[name] = (a, e)
+                taps[name] = (tap_fn(a), tap_fn(e))
             return a, e
 
         # ---- the two branches between WarpAttn calls are independent: `pair` runs one segment of each, the panorama's on a
@@ -311,20 +340,25 @@ class MultiViewBaseModel(nn.Module):
             self._run_pair(pers_fn, pano_fn, (st["x"], st["px"]))
             if dbg is not None:
                 for k in dbx:
-                    dbg[k] = (dbx[k], dbp[k])
+                    dbg[k] = (tap_fn(dbx[k]), tap_fn(dbp[k]))
+                dbx.clear()
+                dbp.clear()
 
         def down_pers(i):
             def fn():
                 db, x = un.down_blocks[i], st["x"]
                 for j in range(len(db.resnets)):
                     x = db.resnets[j].forward_cl(x, emb, f)
-                    dbx[f"res{i}{j}"] = x
+                    if dbg is not None:
+                        dbx[f"res{i}{j}"] = x
                     if db.has_cross_attention:           # DownBlock3D's motion modules are skipped (:292-303)
                         x = db.attentions[j].forward_cl(x, ctx, f)
-                        dbx[f"attn{i}{j}"] = x
+                        if dbg is not None:
+                            dbx[f"attn{i}{j}"] = x
                         if db.motion_modules[j] is not None:
                             x = db.motion_modules[j].forward_cl(x, f)
-                        dbx[f"mm{i}{j}"] = x
+                        if dbg is not None:
+                            dbx[f"mm{i}{j}"] = x
                     skips.append(x)
                 if db.downsamplers is not None:
                     x = db.downsamplers[0].forward_cl(x)
@@ -337,13 +371,16 @@ class MultiViewBaseModel(nn.Module):
                 pdb, px = pu.down_blocks[i], st["px"]
                 for j in range(len(pdb.resnets)):
                     px = pdb.resnets[j].forward_cl(px, pemb, f, pano)
-                    dbp[f"res{i}{j}"] = px
+                    if dbg is not None:
+                        dbp[f"res{i}{j}"] = px
                     if pdb.has_cross_attention:
                         px = pdb.attentions[j].forward_cl(px, pctx, f)
-                        dbp[f"attn{i}{j}"] = px
+                        if dbg is not None:
+                            dbp[f"attn{i}{j}"] = px
                         if pdb.motion_modules[j] is not None:
                             px = pdb.motion_modules[j].forward_cl(px, f)
-                        dbp[f"mm{i}{j}"] = px
+                        if dbg is not None:
+                            dbp[f"mm{i}{j}"] = px
                     pskips.append(px)
                 if pdb.downsamplers is not None:
                     px = pdb.downsamplers[0].forward_cl(px, pano)

@@ -280,31 +280,41 @@ class VersatileAttention(QKVAttention):
         self.is_cross_attention = False
         self.frame_shard = None          # imagine360_amd.dist.FrameShard when frames are split across GPUs
 
-    def frame_pe(self, frames, dtype):
-        """PE rows of this rank's frames [frames, C] in the activation dtype (cached), or None."""
+    def frame_pe(self, frames, dtype, f0=None):
+        """PE rows of ``frames`` frames starting at ``f0`` (default: this rank's first frame) [frames, C] in the activation
+        dtype (cached), or None."""
         if self.pos_encoder is None:
             return None
-        f0 = self.frame_shard.f0 if self.frame_shard is not None else 0
+        if f0 is None:
+            f0 = self.frame_shard.f0 if self.frame_shard is not None else 0
         key = (f0, frames, dtype, self.pos_encoder.pe.device)
         if getattr(self, "_pe_key", None) != key:
             self._pe_key, self._pe_val = key, self.pos_encoder.pe[0, f0:f0 + frames].to(dtype).contiguous()
         return self._pe_val
 
-    def forward(self, tokens, batch, frames, pixels, residual=None, norm=None, stats=None, row_stats=False):
+    def forward(self, tokens, batch, frames, pixels, residual=None, norm=None, stats=None, row_stats=False, frame_major=False):
         """tokens [batch*frames*pixels, C] token-major.  ``norm`` None: ALREADY normalised and with the frame PE added;
         else the block's LayerNorm, applied here together with the PE add -- both folded into the QKV GEMM when the rows'
         statistics ``stats`` are given (the PE rows go through the projection once, as a per-frame table).  ``frames`` =
         frames held by this rank.  ``residual`` is added to the result inside the output projection; ``row_stats``:
-        return (out, statistics of out's rows)."""
+        return (out, statistics of out's rows).
+        ``frame_major``: the rows are ordered (frame, batch, pixel) and hold ALL frames of this rank's pixel range -- the
+        pixel-sharded layout a frame-sharded motion module works in between its two all-to-alls
+        (TemporalTransformer3DModel.forward_cl): the PE row of a token is row // (batch * pixels), no exchange here."""
         c = tokens.shape[-1]
-        sh = self.frame_shard
+        sh = None if frame_major else self.frame_shard
         if norm is None:
             qkv = self.qkv(tokens)
+        elif frame_major:
+            qkv = self.qkv_ln(norm, tokens, stats, post=self.frame_pe(frames, tokens.dtype, f0=0), post_div=batch * pixels)
         else:
             qkv = self.qkv_ln(norm, tokens, stats, post=self.frame_pe(frames, tokens.dtype), post_div=pixels)
-        if sh is None:
+        if frame_major:
+            a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads, frame_major=True)
+        elif sh is None:
             a = kernels.temporal_attention(qkv, batch, frames, pixels, self.heads)
         else:
+            # (attention-boundary exchange, ``FrameShard(boundary="attention")``: round 3's form, 4 C per token and attention)
             # frame-sharded -> pixel-sharded (one all-to-all over xGMI; pack = one kernel), attention over ALL frames reading
             # the receive buffer in place and writing the return trip's send buffer, and back (all-to-all + one unpack kernel)
             q = sh.frames_to_pixels(qkv.reshape(batch, frames, pixels, 3 * c))
@@ -324,10 +334,11 @@ class TemporalTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.ff_norm = nn.LayerNorm(dim)
 
-    def forward(self, y, batch, frames, pixels, stats=None):
-        """``stats``: LayerNorm statistics of y's rows from its producer, or None (see BasicTransformerBlock.forward)."""
+    def forward(self, y, batch, frames, pixels, stats=None, frame_major=False):
+        """``stats``: LayerNorm statistics of y's rows from its producer, or None (see BasicTransformerBlock.forward).
+        ``frame_major``: rows ordered (frame, batch, pixel), see VersatileAttention.forward."""
         for attn, norm in zip(self.attention_blocks, self.norms):
-            y, stats = attn(y, batch, frames, pixels, residual=y, norm=norm, stats=stats, row_stats=True)   # LN, + PE[frame], attention
+            y, stats = attn(y, batch, frames, pixels, residual=y, norm=norm, stats=stats, row_stats=True, frame_major=frame_major)   # LN, + PE[frame], attention
         return self.ff(y, residual=y, ln=self.ff_norm, stats=stats)
 
 
@@ -343,7 +354,11 @@ class TemporalTransformer3DModel(nn.Module):
             temporal_position_encoding) for _ in range(num_layers)])
         self.proj_out = nn.Linear(in_channels, inner)
 
+    frame_shard = None          # imagine360_amd.dist.FrameShard(boundary="module") when frames are split across GPUs
+
     def forward_cl(self, x, frames):
+        if self.frame_shard is not None:
+            return self._forward_pixel_sharded(x, frames, self.frame_shard)
         n, h, w, c = x.shape
         y = self.norm.forward_cl(x).reshape(n * h * w, c)
         y, st = linear(self.proj_in, y, row_stats=True)
@@ -352,6 +367,31 @@ class TemporalTransformer3DModel(nn.Module):
             st = None
         out = linear_residual(self.proj_out, y, x.reshape(n * h * w, c), gn_hw=h * w)
         return kernels.carry_gn(out.reshape(n, h, w, c), out)
+
+    def _forward_pixel_sharded(self, x, frames, sh):
+        """Frame-sharded module with the exchange at the MODULE boundary.  Everything between the
+        module's GroupNorm and its residual add -- proj_in, both (LayerNorm, + frame PE, QKV, attention over frames,
+        out-projection + residual), the feed-forward, proj_out: animatediff/models/motion_module.py:158-185, 230-258 --
+        acts on ONE pixel across frames or on one token, so it runs on pixel-sharded rows of ALL frames: one C-wide
+        all-to-all after the (per-image, hence frame-local) GroupNorm and one C-wide all-to-all in front of the residual
+        add = 2 C per token and module, where the exchange around each attention moved 3 C out + C back, twice = 8 C.
+        x [b * fl, h, w, c] holds this rank's ``frames`` = fl frames; rows between the exchanges are ordered
+        (frame, batch, pixel) over all F frames and this rank's ceil(p / W) pixels (zero rows pad the last rank's range:
+        they pass through the per-row ops and are dropped by the unpack).  Rounding differs from the unsharded path in one
+        place: proj_out's result is rounded to 16 bits before the residual is added (unsharded: the add is fused into the
+        GEMM epilogue and rounds once)."""
+        n, h, w, c = x.shape
+        b, p = n // frames, h * w
+        y = self.norm.forward_cl(x)
+        rows = sh.frames_to_pixels(y.reshape(b, frames, p, c))              # [F * b * pp, c]
+        pp = sh.pixels_per_rank(p)
+        y, st = linear(self.proj_in, rows, row_stats=True)
+        for blk in self.transformer_blocks:
+            y = blk(y, b, sh.total, pp, stats=st, frame_major=True)
+            st = None
+        y = linear(self.proj_out, y)
+        back = sh.pixels_to_frames(y, b, p)                                  # [b, fl, p, c]
+        return back.reshape(n, h, w, c) + x
 
 
 class VanillaTemporalModule(nn.Module):

@@ -16,6 +16,8 @@
 extern "C" {
 #endif
 
+/* 2 since round 5: im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer and the table rows of
+ * im360_linear_ln_fwd include c2 (both introduced in round 4 under version 1).  imagine360_amd/kernels.py refuses a mismatch. */
 int im360_abi_version(void);
 /* bit 0: ablation build (`make ablate`): the rejected A/B kernel variants behind the attn_dbg / attn_hl / attn_hg / attn_ds knobs exist */
 int im360_build_flags(void);

@@ -135,6 +135,64 @@ def gen_masks():
     save("masks.npz", **out)
 
 
+def masks5_samples():
+    """Sampled rows of the (64, 128, 32) bias matrices stored in masks_64x128x32.npz (fixed seed; shared with the tests)."""
+    g = torch.Generator().manual_seed(20260928)
+    ne, nk = 64 * 128, 20 * 32 * 32
+    rows_e = torch.cat([torch.tensor([0, 127, 128, ne // 2 + 64, ne - 128, ne - 1]), torch.randperm(ne, generator=g)[:42]]).sort().values
+    rows_p = torch.cat([torch.tensor([0, 31, 1023, 1024, nk // 2, nk - 1024, nk - 1]), torch.randperm(nk, generator=g)[:41]]).sort().values
+    return rows_e, rows_p
+
+
+def gen_masks5():
+    """Cross-view masks at the level-1 WarpAttn size of BASELINE cfg5 (equirect 64 x 128, 20 views of 32 x 32 -- the largest
+    mask the 1024 x 2048 configuration builds; src/utils/utils.py:12-41 at the shapes of src/models/MVGenModel.py:318-326) from the
+    REAL get_merged_masks: it materialises two 5.4 GB one-hot tensors per variant, which fits the authoring container.  The two
+    8192 x 20 480 matrices per variant do not fit a fixture: stored are 48 sampled rows of each (fp16) plus, over ALL entries,
+    the per-row and per-column sums of (mask + 1) in fp64 -- the background of a mask is exactly -1, so every entry that differs
+    from it moves two of the sums.  The oracle is checked against the reference on the full matrices here."""
+    print("[masks5]")
+    sys.path.insert(0, ref_shims.REF_ROOT)
+    ref_shims.install()
+    from src.utils import utils as RU
+    ph, eh = 32, 64
+    ew, m = 2 * eh, 20
+    ne, npx = eh * ew, ph * ph
+    cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 512).items()}
+    rows_e, rows_p = masks5_samples()
+    out = {"rows_e2p": rows_e, "rows_p2e": rows_p}
+    for tag in ("normal", "oppo"):
+        rnd = 0.9 if tag == "normal" else 0.1
+        orig = RU.random.random
+        RU.random.random = lambda: rnd
+        t0 = time.time()
+        try:
+            pm, em = RU.get_merged_masks(ph, ph, eh, ew, cams, "cpu")
+        finally:
+            RU.random.random = orig
+        print(f"  reference get_merged_masks ({tag}): {time.time() - t0:.0f} s")
+        t0 = time.time()
+        opm, oem = OG.merged_masks(ph, ph, eh, ew, cams, tag == "oppo")
+        print(f"  oracle merged_masks ({tag}): {time.time() - t0:.0f} s")
+        check(f"masks5_pers_{tag}", opm, pm, 1e-5)
+        check(f"masks5_equi_{tag}", oem, em, 1e-5)
+        assert float((opm - pm).abs().max()) < 1e-4 and float((oem - em).abs().max()) < 1e-4
+        del opm, oem
+        e2p = pm.reshape(m, ne, npx).permute(1, 0, 2).reshape(ne, m * npx)          # [Ne, (m h w)]: the model's bias layout
+        p2e = em.reshape(m * npx, ne)
+        del pm, em
+        out[f"e2p_{tag}_rows"] = e2p[rows_e].half()
+        out[f"p2e_{tag}_rows"] = p2e[rows_p].half()
+        for name, mat in (("e2p", e2p), ("p2e", p2e)):
+            d = mat.double() + 1.0
+            out[f"{name}_{tag}_rowsum"] = d.sum(dim=1)
+            out[f"{name}_{tag}_colsum"] = d.sum(dim=0)
+            out[f"{name}_{tag}_minmax"] = torch.tensor([float(mat.min()), float(mat.max())])
+            out[f"{name}_{tag}_background"] = torch.tensor(float((mat == -1).double().mean()))
+        del e2p, p2e
+    save("masks_64x128x32.npz", **out)
+
+
 def gen_ddim():
     print("[ddim]")
     sch = RB.ref_scheduler()
@@ -520,7 +578,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad", "preproc"]      # "pipeline25": ~25 min, "mvfull": ~10 min, "mvfull2": ~80 min, on request
+    which = sys.argv[1:] or ["ops", "masks", "ddim", "vae", "mv", "mvxf", "pipeline", "keys", "srpad", "preproc"]      # "pipeline25": ~25 min, "mvfull": ~10 min, "mvfull2": ~80 min, "masks5": ~12 GB of host memory, on request
     os.makedirs(GOLD, exist_ok=True)
     for w in which:
         globals()["gen_" + w]()

@@ -39,3 +39,27 @@ def record(name, **vals):
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
     except (OSError, ValueError):
         pass
+
+
+def check_masks_64x128x32(tag, e2p, p2e, row_tol=1e-3, sum_rtol=2e-6):
+    """One variant ("normal" / "oppo") of the cross-view bias matrices at the level-1 WarpAttn size of BASELINE cfg5 (equirect
+    64 x 128, 20 views of 32 x 32: e2p [8192, 20480], p2e [20480, 8192], fp32 on any device) against
+    tests/golden/masks_64x128x32.npz -- the REAL get_merged_masks (src/utils/utils.py:12-41; oracle/tools/gen_golden.py masks5):
+    48 sampled rows of each matrix (fp16 in the fixture) and, over ALL entries, per-row / per-column sums of (mask + 1), the
+    background share and the value range.  Returns the observed deviations."""
+    g = gold("masks_64x128x32.npz")
+    obs = {}
+    for name, mat, rows in (("e2p", e2p, g["rows_e2p"]), ("p2e", p2e, g["rows_p2e"])):
+        mat = mat.float()
+        obs[f"{name}_rows_max_abs"] = float((mat[rows.to(mat.device)].cpu() - g[f"{name}_{tag}_rows"].float()).abs().max())
+        d = mat.double() + 1.0
+        rs, cs = g[f"{name}_{tag}_rowsum"], g[f"{name}_{tag}_colsum"]
+        obs[f"{name}_rowsum_rel"] = float((d.sum(dim=1).cpu() - rs).abs().max() / rs.abs().max())
+        obs[f"{name}_colsum_rel"] = float((d.sum(dim=0).cpu() - cs).abs().max() / cs.abs().max())
+        obs[f"{name}_background_diff"] = abs(float((mat == -1).double().mean()) - float(g[f"{name}_{tag}_background"]))
+        lo, hi = (float(v) for v in g[f"{name}_{tag}_minmax"])
+        assert float(mat.min()) == lo and float(mat.max()) == hi, (name, tag, float(mat.min()), float(mat.max()))
+        assert obs[f"{name}_rows_max_abs"] < row_tol, (name, tag, obs)
+        assert obs[f"{name}_rowsum_rel"] < sum_rtol and obs[f"{name}_colsum_rel"] < sum_rtol, (name, tag, obs)
+        assert obs[f"{name}_background_diff"] < 1e-6, (name, tag, obs)
+    return obs

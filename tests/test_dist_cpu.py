@@ -89,36 +89,56 @@ def test_frame_pixel_all_to_all_round_trip():
     assert out[0] and out[1]
 
 
-def _motion_job(rank, world):
+def _motion_job(rank, world, boundary="attention"):
     import _emu_kernels as E
     from imagine360_amd.dist import FrameShard
     from imagine360_amd.layers import to_cl
-    from imagine360_amd.unet3d import VanillaTemporalModule, VersatileAttention
+    from imagine360_amd.unet3d import TemporalTransformer3DModel, VanillaTemporalModule, VersatileAttention
     from imagine360_amd.weights import fill_module_
     mm = VanillaTemporalModule(in_channels=64, num_attention_heads=8, num_transformer_block=1,
                                temporal_position_encoding=True, temporal_position_encoding_max_len=64)
     fill_module_(mm)
     g = torch.Generator().manual_seed(3)
-    x5 = torch.randn(2, 64, 8, 3, 5, generator=g)                 # b c f h w, 8 frames, 15 pixels
+    x5 = torch.randn(2, 64, 8, 3, 5, generator=g)                 # b c f h w, 8 frames, 15 pixels (ragged last pixel shard)
+    sent = []
     with E.patched_kernels():
         full = mm(x5)
-        sh = FrameShard(8)
+        sh = FrameShard(8, boundary=boundary)
+        orig = sh.exchange
+        sh.exchange = lambda send, tag: (sent.append(send.numel()), orig(send, tag))[1]
+        holder = TemporalTransformer3DModel if boundary == "module" else VersatileAttention
         for mod in mm.modules():
-            if isinstance(mod, VersatileAttention):
+            if isinstance(mod, holder):
                 mod.frame_shard = sh
         xl, fl = to_cl(sh.take(x5, 2).contiguous())
         from imagine360_amd.layers import from_cl
         loc = from_cl(mm.forward_cl(xl, fl), fl)
     want = sh.take(full, 2)
-    return float((loc - want).abs().max() / want.abs().max())
+    return [float((loc - want).abs().max() / want.abs().max()), len(sent), sum(sent)]
 
 
-def test_frame_sharded_motion_module_matches_unsharded():
-    out = _run(_motion_job)
-    assert out[0] < 1e-5 and out[1] < 1e-5
+def _motion_job_module(rank, world):
+    return _motion_job(rank, world, "module")
 
 
-def _mv_sharded_job(rank, world):
+@pytest.mark.parametrize("boundary", ["attention", "module"])
+def test_frame_sharded_motion_module_matches_unsharded(boundary):
+    """One motion module, frames cut over two ranks: the exchange around every attention (round 3) and at the module
+    boundary (round 5: GroupNorm frame-sharded -> one C-wide all-to-all -> proj_in ... proj_out on pixel-sharded rows of all
+    frames -> one C-wide all-to-all -> residual add; animatediff/models/motion_module.py:158-185) both reproduce the
+    unsharded module; the module boundary moves a quarter of the bytes in a quarter of the collectives."""
+    out = _run(_motion_job if boundary == "attention" else _motion_job_module)
+    b, fl, pp, c = 2, 4, 8, 64                                   # 15 pixels -> 8 per rank
+    for r in range(2):
+        err, n_exch, elems = out[r]
+        assert err < 1e-5, out[r]
+        if boundary == "module":
+            assert n_exch == 2 and elems == 2 * (2 * fl * b * pp * c), out[r]              # C out, C back
+        else:
+            assert n_exch == 4 and elems == 2 * (2 * fl * b * pp * (3 * c + c)), out[r]    # (3 C out + C back) per attention, two attentions
+
+
+def _mv_sharded_job(rank, world, boundary="module"):
     """Whole dual-branch forward (both UNets, 7 WarpAttn, all motion modules) with the frames cut over the ranks ==
     this rank's frames of the unsharded forward.  Reduced width (channels / 10), 4 frames, 256 x 512 panorama."""
     import random
@@ -135,8 +155,13 @@ def _mv_sharded_job(rank, world):
         torch.manual_seed(3)
         random.seed(3)
         pers_full, pano_full = mv(**kw, **inp)
-        sh = FrameShard(frames)
+        sh = FrameShard(frames, boundary=boundary)
+        n_exch = []
+        orig = sh.exchange
+        sh.exchange = lambda send, tag: (n_exch.append(tag), orig(send, tag))[1]
         mv.set_frame_shard(sh)
+        from imagine360_amd.unet3d import TemporalTransformer3DModel, VersatileAttention
+        holders = [type(m).__name__ for m in mv.modules() if isinstance(m, (TemporalTransformer3DModel, VersatileAttention)) and m.frame_shard is sh]
         torch.manual_seed(3)              # every rank replays the unsharded run's RNG stream (IP noise, WarpAttn coins)
         random.seed(3)
         pers_loc, pano_loc = mv(**kw, **shard_mv_inputs(inp, sh))
@@ -144,7 +169,11 @@ def _mv_sharded_job(rank, world):
         gathered = sh.gather_frames(pano_loc.contiguous(), 2)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     return [rel(pano_loc, sh.take(pano_full, 2)), rel(pers_loc, sh.take(pers_full, 3)), rel(gathered, pano_full),
-            list(pano_loc.shape), list(pers_loc.shape)]
+            list(pano_loc.shape), list(pers_loc.shape), len(n_exch), sorted(set(holders))]
+
+
+def _mv_sharded_job_attention(rank, world):
+    return _mv_sharded_job(rank, world, "attention")
 
 
 def _mv_two_communicators_job(rank, world):
@@ -154,7 +183,7 @@ def _mv_two_communicators_job(rank, world):
     import _emu_kernels as E
     from imagine360_amd import configs, synthetic as S
     from imagine360_amd.dist import FrameShard, frame_shard_pair, shard_mv_inputs
-    from imagine360_amd.unet3d import VersatileAttention
+    from imagine360_amd.unet3d import TemporalTransformer3DModel as Holder
     mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True)
     mv.noise_on_host = True
     frames = 4
@@ -171,8 +200,8 @@ def _mv_two_communicators_job(rank, world):
             random.seed(3)
             outs.append(mv(**kw, **shard_mv_inputs(inp, shards[0])))
             two = mv._shard_two_comms
-            groups = ({id(m.frame_shard.group) for m in mv.pano_unet.modules() if isinstance(m, VersatileAttention)},
-                      {id(m.frame_shard.group) for m in mv.unet.modules() if isinstance(m, VersatileAttention)})
+            groups = ({id(m.frame_shard.group) for m in mv.pano_unet.modules() if isinstance(m, Holder)},
+                      {id(m.frame_shard.group) for m in mv.unet.modules() if isinstance(m, Holder)})
             mv.set_frame_shard(None)
     same = all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     return [same, two, len(groups[0]) == 1 and len(groups[1]) == 1 and groups[0] != groups[1], mv._sharded, mv._shard_two_comms]
@@ -185,11 +214,17 @@ def test_panorama_branch_on_its_own_communicator_matches_one_communicator():
         assert same and two and distinct and not still_sharded and not still_two
 
 
-def test_frame_sharded_mv_forward_matches_unsharded():
-    out = _run(_mv_sharded_job)
+@pytest.mark.parametrize("boundary", ["module", "attention"])
+def test_frame_sharded_mv_forward_matches_unsharded(boundary):
+    """The model runs 32 motion modules per step (16 per UNet: the DownBlock3D / UpBlock3D ones are skipped like in the
+    reference, src/models/MVGenModel.py:292-303, 426-443): 64 all-to-alls with the exchange at the module boundary (the
+    default), 128 around the attentions."""
+    out = _run(_mv_sharded_job if boundary == "module" else _mv_sharded_job_attention)
     for r in range(2):
         assert out[r][0] < 1e-5 and out[r][1] < 1e-5 and out[r][2] < 1e-5, out[r]
         assert out[r][3] == [2, 4, 2, 32, 64] and out[r][4] == [2, 20, 4, 2, 16, 16]
+        assert out[r][5] == (64 if boundary == "module" else 128), out[r]
+        assert out[r][6] == (["TemporalTransformer3DModel"] if boundary == "module" else ["VersatileAttention"]), out[r]
 
 
 def _cfg_split_job(rank, world):
@@ -240,7 +275,8 @@ def _pipeline_sharded_job(rank, world):
     from imagine360_amd.dist import FrameShard
     from imagine360_amd.pipeline import AnimationPipeline
     from imagine360_amd.scheduler import DDIMScheduler
-    from imagine360_amd.unet3d import VersatileAttention
+    from imagine360_amd.unet3d import TemporalTransformer3DModel, VersatileAttention
+    holders = (TemporalTransformer3DModel, VersatileAttention)
     mv = configs.build_mv_model(10, device="cpu", dtype=torch.float32, xformers=True, motion_heads=4)
     vae = configs.build_vae(4, device="cpu", dtype=torch.float32)
     pipe = AnimationPipeline(vae, None, None, mv.unet, mv.pano_unet, mv, DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS), None, "SAM")
@@ -265,13 +301,13 @@ def _pipeline_sharded_job(rank, world):
         part = pipe("synthetic", frame_shard=sh, **kw).videos
         vae.encode = orig
         part_lat = pipe.last_latents[0]
-        unsharded_after = all(m.frame_shard is None for m in mv.modules() if isinstance(m, VersatileAttention))
+        unsharded_after = all(m.frame_shard is None for m in mv.modules() if isinstance(m, holders))
         raised = False
         try:
             pipe("synthetic", frame_shard=sh, **dict(kw, callback=lambda *a: 1 / 0))
         except ZeroDivisionError:
             raised = True
-        clean_after_error = all(m.frame_shard is None for m in mv.modules() if isinstance(m, VersatileAttention))
+        clean_after_error = all(m.frame_shard is None for m in mv.modules() if isinstance(m, holders))
     rel = lambda a, b: float((a - b).norm() / b.norm())
     return [rel(part, full), rel(part_lat, full_lat), sum(encoded), unsharded_after, raised and clean_after_error]
 

@@ -671,6 +671,39 @@ def test_cross_view_masks_and_tables_on_the_device_match_the_reference_fixture()
     assert again[0].data_ptr() == blk.geometry(ph, ph, eh, 2 * eh, cams, False, dev, torch.bfloat16)[0].data_ptr()
 
 
+def test_cross_view_masks_at_the_cfg5_level_1_size_on_the_device():
+    """BASELINE cfg5's largest WarpAttn resolution (equirect 64 x 128, 20 views of 32 x 32; 8192 x 20 480 entries per matrix):
+    the masks built ON THE DEVICE (pano_geometry.cross_view_bias) against the REAL get_merged_masks' fixture, then the cached
+    geometry as the attention kernel receives it for fp16 (packed fp16 * log2 e matrices, both variants) and the spherical
+    positional tables at 640 channels (160 frequencies, top frequency 5000^(159 / 64)) against the oracle's fp32 tables."""
+    from helpers import check_masks_64x128x32
+    from im360_oracle import geometry as OG
+    from imagine360_amd import pano_geometry as G
+    from imagine360_amd.mv_model import WarpAttn
+    dev = torch.device("cuda", 0)
+    cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 512).items()}
+    g = gold("masks_64x128x32.npz")
+    blk = WarpAttn(640).to(dev)
+    obs = {}
+    for tag in ("normal", "oppo"):
+        b_e2p, b_p2e = G.cross_view_bias(32, 32, 64, 128, cams, tag == "oppo", dev)
+        assert b_e2p.is_cuda
+        obs.update({f"{tag}_{k}": v for k, v in check_masks_64x128x32(tag, b_e2p, b_p2e).items()})
+        del b_e2p, b_p2e
+        k_e2p, k_p2e, pers_pe, equi_pe, packed = blk.geometry(32, 32, 64, 128, cams, tag == "oppo", dev, torch.float16)
+        assert packed and k_e2p.dtype == torch.float16 and k_e2p.shape == (8192, 20480) and k_p2e.shape == (20480, 8192)
+        for name, mat, rows in (("e2p", k_e2p, g["rows_e2p"]), ("p2e", k_p2e, g["rows_p2e"])):
+            # packed form = fp16(fp16(mask) * log2 e): undo the scale, allow the two fp16 roundings
+            err = float((mat[rows.to(dev)].float().cpu() / 1.4426950408889634 - g[f"{name}_{tag}_rows"].float()).abs().max())
+            obs[f"{tag}_{name}_packed_rows_max_abs"] = err
+            assert err < 2e-3, (tag, name, err)
+    pc, ec = G.spherical_coords(32, 32, 64, 128, cams)
+    obs["pers_pe_max_abs"] = float((pers_pe.float().cpu() - OG.spherical_pe(pc, 160).reshape(-1, 640)).abs().max())
+    obs["equi_pe_max_abs"] = float((equi_pe.float().cpu() - OG.spherical_pe(ec, 160).reshape(-1, 640)).abs().max())
+    _record("masks_64x128x32_on_the_device", **obs)
+    assert obs["pers_pe_max_abs"] < 1e-3 and obs["equi_pe_max_abs"] < 1e-3, obs          # fp16 table of values in [-1, 1]
+
+
 def test_preprocessing_warps_vs_oracle():
     """SURVEY row N3 on the GPU: im360_remap_cubic_wrap_u8 == the oracle's restatement of cv2.remap(INTER_CUBIC, BORDER_WRAP)
     bit for bit -- random maps incl. coordinates outside the image, exact .5 / integer positions and 1 / 3 / 4 channels --

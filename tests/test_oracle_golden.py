@@ -63,6 +63,18 @@ def test_masks_coords_pe_against_reference():
         assert torch.equal(OG.spherical_pe(ec, nf)[::3, ::5], g[f"equi_pe_{nf}"])
 
 
+def test_masks_at_the_cfg5_level_1_size_against_reference():
+    """The oracle's one-hot construction at equirect 64 x 128 / 20 views of 32 x 32 (the largest mask of BASELINE cfg5) against the
+    REAL get_merged_masks' fixture; the antipodal variant here (gen_golden.py masks5 asserted both variants equal to the
+    reference, max abs 0, while writing the fixture; one of them keeps this test at ~20 s and 6 GB of host memory)."""
+    from helpers import check_masks_64x128x32
+    cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 512).items()}
+    pm, em = OG.merged_masks(32, 32, 64, 128, cams, True)
+    e2p = pm.reshape(20, 8192, 1024).permute(1, 0, 2).reshape(8192, 20480)
+    del pm
+    check_masks_64x128x32("oppo", e2p, em.reshape(20480, 8192))
+
+
 def test_ddim_against_reference():
     g = gold("ddim.npz")
     acp = OD.alphas_cumprod()
