@@ -76,19 +76,28 @@ def _best_threads():
     return best
 
 
-def cpu_baseline_step(mv, args):
-    """The oracle (CPU restatement of the reference path, fp32) timed on ONE FULL-WIDTH denoising step of BASELINE cfg1
-    (8 frames of 256x512: the reference's own CPU-runnable case, 31.9 TFLOP), with the GPU model's weights, on the host
-    cores of this box.  cfg2 itself would take ~8x longer; its figure is the measured cfg1 rate scaled by the analytic
-    FLOP ratio, stated separately."""
+def cpu_baseline_step(mv, args, workload="cfg1", threads="probe"):
+    """The oracle (CPU restatement of the reference path, fp32) timed on ONE FULL-WIDTH denoising step on the host cores of
+    this box, with the GPU model's weights (``mv``; None: the same filler weights built on the CPU).
+    ``workload`` "cfg1" (default: 8 frames of 256x512, the reference's own CPU-runnable case, 31.9 TFLOP, ~1 min): the figure
+    for the benchmarked workload is the measured cfg1 rate scaled by the analytic FLOP ratio, stated separately; "cfg2": the
+    benchmarked workload itself, measured directly (~7 minutes of host time -- `--cpu-baseline
+    cfg2-direct` / tools/cpu_baseline.py, run once per round and committed under profiles/).
+    ``threads``: "probe" (the count a miniature of the step runs fastest on), "all" (os.cpu_count()) or a number."""
     import random
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from im360_oracle import mv as OMV
     from im360_oracle.cfg import sd21_unet_cfg
-    nthreads = _best_threads()
-    w1 = WORKLOADS["cfg1"]
+    if threads == "probe":
+        nthreads = _best_threads()
+    else:
+        nthreads = (os.cpu_count() or 1) if threads == "all" else int(threads)
+        torch.set_num_threads(nthreads)
+    w1 = WORKLOADS[workload]
     cfg = sd21_unet_cfg(args.width_div)
     cfg.xformers = True
+    if mv is None:
+        mv = configs.build_mv_model(args.width_div, device="cpu", dtype=torch.float32, xformers=True)
     sd = {k: v.detach().float().cpu() for k, v in mv.state_dict().items()}
     inp = synthetic.mv_inputs(frames=w1["frames"], pano_hw=w1["pano_hw"], pers_hw=w1["pers_hw"], seed=1, sam_frames=16)
     cams = synthetic.icosahedron_cameras(90, w1["pers_px"])
@@ -126,14 +135,22 @@ def cpu_baseline_step(mv, args):
     f1 = flops.step_flops(frames=w1["frames"], pano_hw=w1["pano_hw"], pers_hw=w1["pers_hw"], block_out_channels=boc)
     w = WORKLOADS[args.workload]
     fw = flops.step_flops(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], block_out_channels=boc)
-    return {"value": (1.0 / dt) * f1 / fw, "unit": "denoising steps/sec", "cores": nthreads, "host_cores": os.cpu_count(), "kind": "port",
+    direct = workload == args.workload
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": (1.0 / dt) * f1 / fw, "unit": "denoising steps/sec", "cores": nthreads, "host_cores": os.cpu_count(), "cpu_model": cpu_model,
+            "threads_chosen_by": threads, "kind": "port",
             "hoisted_work_inside_the_measured_step": dict(hoisted, per_step_work_s=dt_loop,
                                                         value_counting_only_per_step_work=(1.0 / dt_loop) * f1 / fw),
-            "sample": f"ONE full-width oracle step of BASELINE cfg1 (8 frames, 256x512 equirect, CFG batch 2, "
+            "sample": f"ONE full-width oracle step of BASELINE {workload} ({w1['frames']} frames, {w1['pano_hw'][0] * 8}x{w1['pano_hw'][1] * 8} equirect, CFG batch 2, "
                       f"{f1 / 1e12:.1f} TFLOP incl. the IP-adapter conditioning and mask building the GPU path hoists): "
                       f"measured {dt:.1f} s on {nthreads} threads of the box's {os.cpu_count()} logical cores = {f1 / dt / 1e12:.3f} TFLOP/s",
-            "measured_cfg1_s_per_step": dt, "measured_cfg1_steps_per_s": 1.0 / dt,
-            "extrapolation": f"value = measured cfg1 steps/s x ({f1 / 1e12:.1f} / {fw / 1e12:.1f}) analytic FLOP ratio to {args.workload}"}
+            f"measured_{workload}_s_per_step": dt, f"measured_{workload}_steps_per_s": 1.0 / dt,
+            "extrapolation": ("none: the benchmarked workload itself was timed" if direct else
+                              f"value = measured {workload} steps/s x ({f1 / 1e12:.1f} / {fw / 1e12:.1f}) analytic FLOP ratio to {args.workload}")}
 
 
 def cpu_baseline_sample(args):
@@ -203,8 +220,10 @@ def main(argv=None):
     ap.add_argument("--parallelism", default="samples", choices=["samples", "frames", "cfgxframes"])
     ap.add_argument("--width-div", type=int, default=1, help="debug only: reduced-width model (INVALID as a benchmark)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--cpu-baseline", default="step", choices=["step", "sample", "none"],
-                    help="step: one full-width cfg1 oracle step on the host cores (~1 min); sample: bounded block sample (~10 s)")
+    ap.add_argument("--cpu-baseline", default="step", choices=["step", "sample", "none", "cfg2-direct"],
+                    help="step: one full-width cfg1 oracle step on the host cores (~1 min) scaled to the workload by the FLOP ratio; "
+                         "cfg2-direct: one oracle step of the benchmarked workload itself (~7 min); sample: bounded block sample (~10 s)")
+    ap.add_argument("--cpu-threads", default="probe", help="host threads of the CPU baseline: probe (fastest on a miniature of the step), all (os.cpu_count()), or a number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="hipBLASLt default heuristic instead of the shipped solution table")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
@@ -433,6 +452,8 @@ def main(argv=None):
             "step_changed_the_latents_rel": relf(g_pano, p0),
         }
         kernels.STATS, kernels.SHAPES = saved_counters
+        parity_check["status"] = ("bit-identical" if parity_check["graph_dual_vs_eager_bit_identical"] else
+                                  "DIFFERS from the eager one-stream step (every recorded run was bit-identical: investigate)")
         if parity_check["graph_dual_vs_eager_rel"] > 1e-3:      # (bit-identical in practice; hipBLASLt may pick another solution under capture)
             raise SystemExit(f"bench.py: the benchmarked launch mode disagrees with the eager single-stream step: {parity_check}")
 
@@ -555,8 +576,18 @@ def main(argv=None):
                                 "algorithmic_tflop_per_step": a["algorithmic_tflop_per_step"],
                                 "note": "QK^T + PV flops of every attn_fwd launch (self, text + IP cross, WarpAttn) over their summed time"}
         if world == 1 and args.cpu_baseline != "none":
-            out["cpu_baseline"] = cpu_baseline_step(mv, args) if args.cpu_baseline == "step" else cpu_baseline_sample(args)
+            if args.cpu_baseline == "sample":
+                out["cpu_baseline"] = cpu_baseline_sample(args)
+            else:
+                out["cpu_baseline"] = cpu_baseline_step(mv, args, workload=args.workload if args.cpu_baseline == "cfg2-direct" else "cfg1", threads=args.cpu_threads)
             out["speedup_vs_cpu_baseline"] = steps_per_s / out["cpu_baseline"]["value"]
+            # the direct measurement of the benchmarked workload on a box of this pool (tools/cpu_baseline.py, once per round)
+            direct = os.path.join(ROOT, "profiles", "r05_cpu_baseline_cfg2_direct.json")
+            if os.path.isfile(direct) and args.workload == "cfg2" and args.cpu_baseline != "cfg2-direct":
+                try:
+                    out["cpu_baseline"]["cfg2_measured_directly"] = json.load(open(direct))
+                except (ValueError, OSError):
+                    pass
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -166,6 +166,8 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
     if out is None:
         assert not accumulate
         out = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    else:
+        _written(out)
     assert out.stride(2) == 1
     if bias is not None:
         assert bias.shape == (Nq, Nk) and bias.stride(1) == 1 and bias.dtype == (torch.float16 if bias_packed else q.dtype)
@@ -216,6 +218,8 @@ def temporal_attention(qkv, B, F, P, heads, frame_major=False, out=None):
     rs = qkv.stride(0)
     if out is None:
         out = torch.empty((B * F * P, C), dtype=qkv.dtype, device=qkv.device)
+    else:
+        _written(out)
     assert out.shape == (B * F * P, C) and out.is_contiguous() and out.dtype == qkv.dtype
     d = C // heads
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
@@ -234,6 +238,7 @@ def shard_pack(src, dst, B, Fl, P, W, PP, unpack=False):
     _dev(src, dst)
     C = src.shape[-1]
     assert src.is_contiguous() and dst.is_contiguous() and dst.shape[-1] == C and src.dtype == dst.dtype and src.element_size() == 2
+    _written(dst)
     tok, buf = (dst, src) if unpack else (src, dst)
     assert tok.numel() == B * Fl * P * C and buf.numel() == W * Fl * B * PP * C, (tok.shape, buf.shape)
     rc = lib().im360_shard_pack(_p(src), _p(dst), B, Fl, P, C, W, PP, int(bool(unpack)), _stream())
@@ -259,6 +264,14 @@ def _gn_of(t):
 
 def _tag_gn(t, partial, slabs):
     t._im360_gn = (partial, slabs, t._version)
+    return t
+
+
+def _written(t):
+    """The ctypes kernels write through raw pointers and do not bump ``t._version`` (the tag's invalidation rule): every wrapper
+    that writes into a CALLER-SUPPLIED tensor (``out=`` / ``accumulate`` / a destination buffer) drops a producer tag it may carry."""
+    if t is not None and getattr(t, "_im360_gn", None) is not None:
+        del t._im360_gn
     return t
 
 
@@ -639,6 +652,8 @@ def softmax_rows(x, scale=1.0, out=None):
     assert x.dim() == 2 and x.stride(1) == 1
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _written(out)
     rc = lib().im360_softmax_rows(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(scale),
                                   _dt(x), _stream())
     _check(rc, "im360_softmax_rows")

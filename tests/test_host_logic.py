@@ -5,6 +5,7 @@ checked against fixtures generated from the REAL reference.  fp32 -> relative L2
 import json
 import os
 import random
+import re
 
 import pytest
 import torch
@@ -17,6 +18,7 @@ from imagine360_amd.scheduler import DDIMScheduler
 
 torch.set_grad_enabled(False)
 TOL = 5e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -484,3 +486,80 @@ def test_measurement_tools_parse_what_they_claim(tmp_path):
     assert "# 4 dispatches over 1 step(s)" in out
     ring = [ln for ln in out.splitlines() if "conv_ring_kernel" in ln and "grid=" in ln]
     assert len(ring) == 1 and ring[0].split()[0] == "0.002" and "grid=(256, 1, 1) x 512" in ring[0], ring
+
+
+def test_caller_supplied_outputs_drop_a_producer_tag():
+    """the ctypes kernels do not bump Tensor._version, so every wrapper that writes into a caller-supplied tensor
+    drops a GroupNorm producer tag the tensor may carry (kernels._written)."""
+    import inspect
+    from imagine360_amd import kernels as K
+    t = torch.zeros(4)
+    K._tag_gn(t, torch.zeros(1), 1)
+    assert K._gn_of(t) is not None
+    assert K._written(t) is t and K._gn_of(t) is None and K._written(None) is None
+    for fn in (K.attention, K.temporal_attention, K.softmax_rows, K.shard_pack):
+        assert "_written(" in inspect.getsource(fn), fn.__name__
+
+
+def test_tool_patches_apply_to_the_tree():
+    """tools/patches/* (the cycle-stamp instrumentation of the ring kernel, tools/stamps_probe.py) must apply to HEAD."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch")))
+    assert patches
+    tmp = tempfile.mkdtemp()
+    try:
+        # (works without a .git directory: the patched file is copied into a scratch tree and `patch --dry-run` is asked)
+        for p in patches:
+            text = open(p).read()
+            files = re.findall(r"^\+\+\+ b/(\S+)", text, re.M)
+            assert files, p
+            for f in files:
+                os.makedirs(os.path.dirname(os.path.join(tmp, f)), exist_ok=True)
+                shutil.copy(os.path.join(ROOT, f), os.path.join(tmp, f))
+            r = subprocess.run(["patch", "-p1", "--dry-run", "-F0", "-i", p], cwd=tmp, capture_output=True, text=True)
+            assert r.returncode == 0, (p, r.stdout[-400:], r.stderr[-400:])
+    finally:
+        shutil.rmtree(tmp)
+
+
+def test_newest_rocprof_summary_names_kernels_the_shipped_library_contains():
+    """profiles/ must describe the code that ships.  Every im360 kernel symbol in the kernel-statistics summaries
+    of the newest round (tools/profile_bench.sh keeps the names mangled) has to exist in the gfx950 code objects of
+    imagine360_amd/libim360_kernels.so -- a summary taken before a kernel's template arguments changed fails here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(f"{tools}/llvm-objdump"):
+        pytest.skip("ROCm LLVM binutils not installed")
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.csv"))
+    rounds = {f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)) for f in files}
+    newest = max(rounds.values())
+    assert newest >= 5, "no rocprofv3 summary of this round's library under profiles/ (tools/profile_bench.sh)"
+    tmp = tempfile.mkdtemp()
+    try:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(os.path.join(ROOT, "imagine360_amd", "libim360_kernels.so"), so)
+        subprocess.run([f"{tools}/llvm-objdump", "--offloading", so], capture_output=True, cwd=tmp, check=True)
+        have = set()
+        for f in glob.glob(so + ".*gfx950"):
+            syms = subprocess.run([f"{tools}/llvm-objdump", "-t", f], capture_output=True, text=True, check=True).stdout
+            have.update(re.findall(r"\b(_ZN5im360\w+)", syms))
+    finally:
+        shutil.rmtree(tmp)
+    assert len(have) > 100, len(have)
+    checked = 0
+    for f in sorted(k for k, v in rounds.items() if v == newest):
+        lines = [l for l in open(f) if not l.startswith("#")]
+        names = [r["Name"].split(".kd")[0] for r in csv.DictReader(lines)]
+        ours = [n for n in names if n.startswith("_ZN5im360")]
+        assert len(ours) >= 20, (f, "kernel names must be mangled (rocprofv3 -M) and cover the step", len(ours))
+        missing = [n for n in ours if n not in have]
+        assert not missing, (os.path.basename(f), missing[:5])
+        checked += len(ours)
+    assert checked >= 20

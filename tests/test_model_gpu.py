@@ -389,7 +389,7 @@ def test_full_width_cfg2_step_vs_reference_fixture_in_every_launch_mode(dt):
     CFG batch 2 -- src/models/MVGenModel.py:59-481 at the shapes of configs/prompt-dual.yaml:59-72):
     (1) one dual-branch forward against what the REAL reference computed in fp32 for the same bf16-rounded weights, inputs and
         seeds (tests/golden/mv_forward_full_cfg2.npz, oracle/tools/gen_golden.py mvfull2: 17 minutes of host time there), within
-        1.25x of what 16-bit storage alone costs on this network (the fixture's calibration);
+        1.12x of what 16-bit storage alone costs on this network (the fixture's calibration; observed 1.04 - 1.06x);
     (2) the same forward issued eagerly with the panorama branch on the side stream (opt-in mode; recorded, not asserted);
     (3) one whole denoising step (forward + CFG + DDIM) replayed from the captured two-stream hipGraph -- the launch mode
         bench.py times -- against the step issued eagerly on one stream from the same latents and RNG states."""
@@ -452,10 +452,108 @@ def test_full_width_cfg2_step_vs_reference_fixture_in_every_launch_mode(dt):
     errs["graph_bit_identical"] = bool(torch.equal(g_pano, e_pano) and torch.equal(g_pers, e_pers))
     errs["step_moved_the_latent"] = rel(g_pano, p0)
     _record(f"full_width_cfg2_step_{str(dt).split('.')[-1]}", **errs)
-    assert errs["pano"] <= 1.25 * cal_pano + 2e-4 and errs["pers"] <= 1.25 * cal_pers + 2e-4, errs
+    # (1.12x the storage-only error -- observed 1.04 - 1.06x -- so that a regression of one kernel family cannot hide)
+    assert errs["pano"] <= 1.12 * cal_pano + 1e-4 and errs["pers"] <= 1.12 * cal_pers + 1e-4, errs
     assert errs["worst_view"] <= 2 * cal_pers + 2e-4 and errs["worst_pano_frame"] <= 2 * cal_pano + 2e-4, errs
-    assert errs["graph_two_streams_vs_eager_pano"] < 1e-5 and errs["graph_two_streams_vs_eager_pers"] < 1e-5, errs
+    assert errs["graph_bit_identical"], errs                 # (bit identity, which is what every recorded run showed)
     assert errs["step_moved_the_latent"] > 1e-2, errs
+
+
+# ------------------------------------------------------------------ whole steps at BASELINE cfg4 / cfg5 size
+_BIG = {"cfg4": dict(frames=48, pano_hw=(64, 128), pers_hw=(32, 32), px=256, dt=torch.bfloat16),
+        "cfg5": dict(frames=16, pano_hw=(128, 256), pers_hw=(64, 64), px=512, dt=torch.float16)}
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+def test_whole_denoising_step_at_cfg4_and_cfg5_size(name):
+    """ONE WHOLE full-width denoising step (src/models/MVGenModel.py:59-481 + CFG + DDIM) at the sizes of BASELINE cfg4 (48 frames
+    of 512 x 1024, bf16: the 17 - 64 frame temporal kernels, 3x the token counts of cfg2) and cfg5 (16 frames of 1024 x 2048, fp16:
+    32 768-token panorama self-attention, 8192 x 20 480 WarpAttn masks, 4x the token counts) on one GPU.  No CPU reference fits
+    these sizes (1288 TFLOP per step); what is asserted is size-independent:
+    (1) the step replayed from the captured two-stream hipGraph == the step issued eagerly on one stream, BIT FOR BIT, from the
+        same latents and RNG states (graph capture, routing thresholds, mask / PE tables and every kernel at these shapes);
+    (2) CFG-row independence: with the conditioning of row 0 copied into row 1 the two rows of every prediction agree to far
+        below the storage error (rows are separate images / token ranges of every kernel; hipBLASLt may pick position-dependent
+        split-K orders, hence a bound instead of equality);
+    (3) longitude rotation: with the seven WarpAttn blocks at their reference initialisation (zero output projections,
+        src/modules/transformer.py:30-32, 55-57: exact identities) the panorama branch is the circularly padded UNet alone, and
+        rolling the input latent along W rolls the prediction -- up to the 16-bit rounding of two different evaluations and the
+        reference's own padded GroupNorm statistics (pad_pano(2) weighs four columns twice, MVGenModel.py:276-281, so the
+        reference is not exactly equivariant either).  A wrong wrap / seam at any of the 4 resolutions shows as a spike in the
+        per-column error profile."""
+    from imagine360_amd.graph_step import GraphedDenoiseStep
+    w = _BIG[name]
+    dt, dev = w["dt"], torch.device("cuda", 0)
+    tag = f"whole_step_{name}_{str(dt).split('.')[-1]}"
+    mv = configs.build_mv_model(1, device=dev, dtype=dt, xformers=True)
+    inp = S.mv_inputs(frames=w["frames"], pano_hw=w["pano_hw"], pers_hw=w["pers_hw"], seed=1, sam_frames=max(16, w["frames"]), dtype=dt, device=dev)
+    cams = S.icosahedron_cameras(90, w["px"], device=dev)
+    sch = DDIMScheduler(**configs.NOISE_SCHEDULER_KWARGS)
+    sch.set_timesteps(25)
+    ts = sch._timesteps_host
+    kw = dict(cameras=cams, use_fps_condition=True, use_ip_plus_cross_attention=True)
+    errs = {}
+    # ---- (1) captured two-stream graph == eager one-stream step
+    ginp = {k: v.clone() for k, v in inp.items() if k != "timestep"}
+    p0, q0 = ginp["pano_latent"][:1, :4].clone(), ginp["latents"][:1, :, :4].clone()
+    mv.dual_stream = True
+    gs = GraphedDenoiseStep(mv, sch, ginp, cams, p0, q0, 7.5, warmup=1)
+    py_state, dev_state = random.getstate(), torch.cuda.get_rng_state(dev)
+    gs.step(ts[3])
+    torch.cuda.synchronize()
+    g_pano, g_pers = gs.pano_lat.clone(), gs.pers_lat.clone()
+    del gs, ginp
+    torch.cuda.empty_cache()
+    mv.dual_stream = False
+    random.setstate(py_state)
+    torch.cuda.set_rng_state(dev_state, dev)
+    einp = {k: v.clone() for k, v in inp.items()}
+    einp["pano_latent"][:, :4] = p0
+    einp["latents"][:, :, :4] = q0
+    einp["timestep"] = torch.tensor([ts[3]], dtype=torch.int64, device=dev)
+    pp, pn = mv(**kw, **einp)
+    e_pano = sch.fused_cfg_step(pn[0:1], pn[1:2], 7.5, ts[3], p0)
+    e_pers = sch.fused_cfg_step(pp[0:1], pp[1:2], 7.5, ts[3], q0)
+    errs["graph_two_streams_vs_eager_pano"], errs["graph_two_streams_vs_eager_pers"] = rel(g_pano, e_pano), rel(g_pers, e_pers)
+    errs["graph_bit_identical"] = bool(torch.equal(g_pano, e_pano) and torch.equal(g_pers, e_pers))
+    errs["finite"] = bool(torch.isfinite(g_pano.float()).all() and torch.isfinite(g_pers.float()).all())
+    errs["step_moved_the_latent"] = rel(g_pano, p0)
+    del pp, pn, g_pers, e_pers
+    # ---- (2) CFG-row independence (IP-adapter noise off: it is drawn per row)
+    mv._ip_noise = lambda like: torch.zeros_like(like)
+    m = einp["latents"].shape[1]
+    rinp = {}
+    for k, v in einp.items():
+        if k != "timestep" and v.dim() >= 1 and v.shape[0] in (2, 2 * m):
+            half = v.shape[0] // 2
+            # (the perspective SAM features are ONE tensor expanded over the views, stride 0: keep them a view)
+            v = v[:1].expand(v.shape) if (half == 1 and 0 in v.stride()) else torch.cat([v[:half], v[:half]]).contiguous()
+        rinp[k] = v
+    pp, pn = mv(**kw, **rinp)
+    errs["cfg_rows_pano"], errs["cfg_rows_pers"] = rel(pn[1], pn[0]), rel(pp[1], pp[0])
+    del pp, pn, rinp
+    # ---- (3) longitude rotation of the panorama branch with the WarpAttn blocks at their (identity) initialisation
+    for blk in list(mv.cp_blocks_encoder) + [mv.cp_blocks_mid] + list(mv.cp_blocks_decoder):
+        for prm in (blk.transformer.attn1.to_out.weight, blk.transformer.attn1.to_out.bias, blk.transformer.ff.net[2].weight, blk.transformer.ff.net[2].bias):
+            prm.data.zero_()
+    W = w["pano_hw"][1]
+    shift = W // 4 + 3
+    _, pn_a = mv(**kw, **einp)
+    pn_a = pn_a.clone()
+    rolled = dict(einp, pano_latent=torch.roll(einp["pano_latent"], shift, dims=-1).contiguous())
+    _, pn_b = mv(**kw, **rolled)
+    want = torch.roll(pn_a, shift, dims=-1)
+    errs["rotation_rel"] = rel(pn_b, want)
+    col = ((pn_b.float() - want.float()) ** 2).sum(dim=(0, 1, 2, 3)).sqrt() / (want.float() ** 2).sum(dim=(0, 1, 2, 3)).sqrt()
+    errs["rotation_worst_column_over_median"] = float(col.max() / col.median())
+    errs["rotation_moved_the_prediction"] = rel(pn_b, pn_a)
+    _record(tag, **errs)
+    half = dt == torch.float16
+    assert errs["finite"] and errs["graph_bit_identical"], errs
+    assert errs["step_moved_the_latent"] > 3e-3, errs
+    assert errs["cfg_rows_pano"] < (1e-3 if half else 6e-3) and errs["cfg_rows_pers"] < (1e-3 if half else 6e-3), errs
+    assert errs["rotation_rel"] < (1.5e-2 if half else 4e-2), errs
+    assert errs["rotation_worst_column_over_median"] < 2.5 and errs["rotation_moved_the_prediction"] > 0.5, errs
 
 
 def test_cfg5_sized_kernels_fp16():
