@@ -1680,6 +1680,15 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
                 }
                 return;
             }
+            if (variant == 11) {                        // the same with a CHUNK-MAJOR weight operand (the caller repacked it: kernels.chunk_major)
+                if constexpr (EPI == 1 || EPI == 4) {
+                    hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 0, true>), dim3(grid), dim3(512), 0, stream, p);
+                } else {
+                    if (p.res) hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 1, true>), dim3(grid), dim3(512), 0, stream, p);
+                    else hipLaunchKernelGGL((gemm_a3_kernel<T, TN, EPI, G, 2, true>), dim3(grid), dim3(512), 0, stream, p);
+                }
+                return;
+            }
         }
 #endif
         if constexpr (EPI == 1 || EPI == 4) {
@@ -1998,7 +2007,7 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     ProfScope prof(PROF_GEMM, stream);
     const int kr = knob(KNOB_CONV_RING);
     const int v = kr == 5 ? 1 : (kr == 7 ? 6 : kr);
-    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, (v == 8 || v == 10) ? v : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, (v == 8 || v == 10) ? v : 1);
+    if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1);
     return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);
 }
 
@@ -2029,7 +2038,7 @@ extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const vo
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10) ? knob(KNOB_CONV_RING) : 1;
+    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10 || knob(KNOB_CONV_RING) == 11) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 5, 3, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 5, 3, true>(p, (hipStream_t)stream, v6);
 }
 
@@ -2054,7 +2063,7 @@ extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const 
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10) ? knob(KNOB_CONV_RING) : 1;
+    const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10 || knob(KNOB_CONV_RING) == 11) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);
 }
 

@@ -21,7 +21,11 @@
 // its C intervals one interval earlier in its own frame, waits at the end of its R intervals).  vmcnt retires in order, so each
 // wait names how many YOUNGER requests may stay in flight: the B half always goes out in front of the A stage of the same
 // interval, and A (st + 2) stays in flight across both waits of stage st.  Same accumulation order as every other loop.
-template <typename T, int TN, int EPI, bool GNS = false, int RESM = 0>
+// BCM (round 5, knob conv_ring 11): the weight operand arrives CHUNK-MAJOR -- [K / 32][rows][32 channels] instead of [rows][K] -- so that a
+// 32-channel half stage of the tile is one contiguous 20 KB block and every LDS-DMA instruction of a wave covers whole 128-byte
+// lines (two 64-byte rows per line) instead of 64-byte row segments: round 4 measured those at half the L2 -> LDS rate
+// (profiles/r04_dma_seg_probe.txt) and blamed them for this kernel's 3 - 15 % deficit.  Same LDS image, same arithmetic.
+template <typename T, int TN, int EPI, bool GNS = false, int RESM = 0, bool BCM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void gemm_a3_kernel(ConvParams p) {
     constexpr int NT = 512, WN = 2, TM = 2, BM = 256, BN = WN * TN * 32;
     constexpr int TILE_A = BM * 128, TILE_BH = BN * 64;
@@ -67,11 +71,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     const T* aptr[4];
     uint32_t amask = 0;
     const T* bptr = wg;
-    const long bstride = 128L * K;
+    const long wrows = ((long)p.Cout + 127) / 128 * 128;              // rows of the packed weight (im360_pack_conv_weight pads to 128)
+    const long bstride = BCM ? 128L * 32 : 128L * K;
+    const long bhalf = BCM ? wrows * 32 : 32;                         // elements between consecutive 32-channel half stages
     auto init_tile = [&](long tile) {
         const long m0 = tile_m0(tile);
         const int n0 = tile_n0(tile);
-        bptr = wg + (long)(n0 + srowB) * K + pdB;
+        bptr = BCM ? wg + (long)(n0 + srowB) * 32 + pdB : wg + (long)(n0 + srowB) * K + pdB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = m0 + srowA + i * 64;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
     auto issue_a = [&](int slot) { static_for<4>([&](auto ic) { piece_a(slot, ic); }); };
     auto issue_b = [&](int slot) {
         static_for<NBP>([&](auto ic) { piece_b(slot, ic); });
-        bptr += 32;
+        bptr += bhalf;
     };
     const int nb = B3 ? (wid_s < 4 ? 3 : 2) : 2;  // this wave's requests per half stage
     auto wait_vm = [&](int n) {                   // at most n of this wave's youngest requests may still be in flight
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            if (grp && rb3) bptr += 32;
+            if (grp && rb3) bptr += bhalf;
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (!grp) wait_vm(c0);
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void g
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            if (grp && rb4) bptr += 32;
+            if (grp && rb4) bptr += bhalf;
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (!grp && rb2) wait_vm(c1);

@@ -9,7 +9,9 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libim360_kernels.so")
+# IM360_KERNELS_LIB: another build of the SAME library for the A/B tools (`make -C csrc ablate-lib` -> libim360_kernels_ablate.so:
+# the shipped kernels plus the measured-and-rejected variants); never a different implementation
+_LIB_PATH = os.environ.get("IM360_KERNELS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libim360_kernels.so")
 _lib = None
 
 _I64, _F32, _INT, _PTR = ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p
@@ -418,6 +420,15 @@ def pack_conv_up2_weight(w):
     _dev(w)
     w4 = up2_weights(w).to(w.dtype)
     return torch.stack([pack_conv_weight(w4[i].contiguous()) for i in range(4)]).contiguous()
+
+
+def chunk_major(w_packed):
+    """Packed token-major weight [rows, 1, K] (``pack_conv_weight`` / ``pack_geglu``) -> the same elements in CHUNK-MAJOR order
+    [K / 32][rows][32] (returned with the original shape): the operand layout of the A/B kernel behind knob conv_ring 11, where a
+    32-channel half stage of a weight tile is one contiguous block of whole 128-byte lines."""
+    r, t, k = w_packed.shape
+    assert t == 1 and k % 32 == 0
+    return w_packed.reshape(r, k // 32, 32).permute(1, 0, 2).contiguous().reshape(r, 1, k)
 
 
 def conv_up2(x, w4_packed, cout, bias=None, wrap=False):

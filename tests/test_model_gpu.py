@@ -535,7 +535,7 @@ def test_whole_denoising_step_at_cfg4_and_cfg5_size(name):
     # ---- (3) longitude rotation of the panorama branch with the WarpAttn blocks at their (identity) initialisation
     for blk in list(mv.cp_blocks_encoder) + [mv.cp_blocks_mid] + list(mv.cp_blocks_decoder):
         for prm in (blk.transformer.attn1.to_out.weight, blk.transformer.attn1.to_out.bias, blk.transformer.ff.net[2].weight, blk.transformer.ff.net[2].bias):
-            prm.data.zero_()
+            prm.zero_()                    # (in place ON the parameter: bumps its version, the packed-weight caches rebuild)
     W = w["pano_hw"][1]
     shift = W // 4 + 3
     _, pn_a = mv(**kw, **einp)

@@ -12,13 +12,19 @@ from imagine360_amd import kernels as K  # noqa: E402
 from tools.bench_kernels import timeit, rn  # noqa: E402
 
 iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
-VARIANTS = [1, 10]          # 1 = default (staggered 64-channel stages), 10 = two activation stages in flight (gemm_a3_kernel); 8 = round 3 ring
+VARIANTS = [1, 10, 11]      # 1 = default (staggered 64-channel stages), 10 = two activation stages in flight (gemm_a3_kernel), 11 = the same
+                            # with the weight operand chunk-major (whole-line half stages; round 5); 8 = round 3 ring
+if "--variants" in sys.argv:
+    VARIANTS = [int(v) for v in sys.argv[sys.argv.index("--variants") + 1].split(",")]
 
 
-def ab(name, fn, fl):
+def ab(name, make, fl, wp):
+    """make(weight) -> the launch closure; variant 11 gets the chunk-major repack of the weight operand (kernels.chunk_major)."""
     outs, row = [], []
+    wcm = K.chunk_major(wp) if 11 in VARIANTS else None
     for v in VARIANTS:
         K.tuning_set("conv_ring", v if v != 6 or not name.startswith("conv") else 7)
+        fn = make(wcm if v == 11 else wp)
         y = fn()
         y = y[0] if isinstance(y, tuple) else y
         outs.append(y.clone())
@@ -38,13 +44,14 @@ for name, M, Kd, N in ([] if ("--only-ablate" in sys.argv or "--only" in sys.arg
     fl = 2.0 * M * Kd * N
     t0 = timeit(lambda: F.linear(x, w, b), iters)
     print(f"{name:34s} hipBLASLt {t0 * 1e3:7.3f} ms {fl / t0 / 1e12:6.0f} TF/s")
-    ab("linear " + name, lambda: K.linear(x, wp, N, bias=b, res=r), fl)
-    ab("linear+rowstats " + name, lambda: K.linear(x, wp, N, bias=b, res=r, row_stats=True), fl)
+    ab("linear " + name, lambda wq: (lambda: K.linear(x, wq, N, bias=b, res=r)), fl, wp)
+    ab("linear+rowstats " + name, lambda wq: (lambda: K.linear(x, wq, N, bias=b, res=r, row_stats=True)), fl, wp)
+    ab("linear nores " + name, lambda wq: (lambda: K.linear(x, wq, N, bias=b)), fl, wp)
     del x, w, b, r, wp
 for name, M, C in ([] if ("--only-ablate" in sys.argv or "--only" in sys.argv) else [("pers L0", 655360, 320), ("pano L0", 262144, 320), ("pers L1", 163840, 640), ("pers L2", 40960, 1280)]):
     x, w, b = rn(M, C), rn(8 * C, C) * C ** -0.5, rn(8 * C)
     wp, bp = K.pack_geglu(w, b)
-    ab("geglu " + name, lambda: K.linear_geglu(x, wp, bp, 4 * C), 2.0 * M * C * 8 * C)
+    ab("geglu " + name, lambda wq: (lambda: K.linear_geglu(x, wq, bp, 4 * C)), 2.0 * M * C * 8 * C, wp)
     del x, w, b, wp, bp
 if "--conv" in sys.argv:
     for name, N, H, W, Cin, Cout, kw in [("pers L0 320->320", 640, 32, 32, 320, 320, {}), ("pers L0 640->320", 640, 32, 32, 640, 320, {}),

@@ -32,7 +32,7 @@ for mode in 1stream 2stream; do
     fi
     grep '^{"metric"' $D/bench_stdout.log | tail -1 > $OUT/${tag}_profiled.json
     if [ $mode = 1stream ] && [ -n "$trace" ]; then
-        python $R/tools/trace_by_shape.py "$trace" --steps 1 > $OUT/r05_${HASH}_step_by_shape.txt 2>> $D/bench_stdout.log
+        python $R/tools/trace_by_shape.py "$trace" --steps 1 --skip-steps 1 > $OUT/r05_${HASH}_step_by_shape.txt 2>> $D/bench_stdout.log
     fi
     find $D -name "*kernel_trace.csv" -delete
     find $D -name "*.db" -delete

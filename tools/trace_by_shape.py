@@ -36,13 +36,18 @@ def main():
     ap.add_argument("--end-kernel", default="cfg_ddim", help="kernel whose launches end a step (2 per step)")
     ap.add_argument("--per-step", type=int, default=2)
     ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--skip-steps", type=int, default=0,
+                    help="trailing steps to leave out (bench.py ends with its parity check: replayed graph, eager one-stream step, eager "
+                         "TWO-stream step -- `--skip-steps 1` tabulates the eager one-stream step, where every kernel has the chip alone)")
     args = ap.parse_args()
     rows = list(csv.DictReader(open(args.csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [i for i, r in enumerate(rows) if args.end_kernel in r["Kernel_Name"]]
     need = args.steps * args.per_step
-    assert len(ends) > need, (len(ends), need)
-    lo, hi = ends[-need - 1] + 1, ends[-1] + 1
+    skip = args.skip_steps * args.per_step
+    assert len(ends) > need + skip, (len(ends), need, skip)
+    last = len(ends) - 1 - skip
+    lo, hi = ends[last - need] + 1, ends[last] + 1
     rows = rows[lo:hi]
     agg = collections.defaultdict(lambda: [0, 0])
     for r in rows:
