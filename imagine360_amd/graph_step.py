@@ -60,10 +60,17 @@ class GraphedDenoiseStep:
         mv.draw_coins(dev)                       # allocates the device coin buffer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # eager warm-up off the default stream (caches, allocator)
-            self._upload(scheduler._timesteps_host[0], draw=False)
-            for _ in range(warmup):
-                self._body()
+        #  the warm-up issues the step the way the capture will: with the panorama branch on the model's side stream when
+        # dual_stream is set, so that stream's allocator pool and GEMM workspaces exist before the capture begins
+        was_eager = getattr(mv, "dual_stream_eager", False)
+        mv.dual_stream_eager = bool(getattr(mv, "dual_stream", False))
+        try:
+            with torch.cuda.stream(side):            # eager warm-up off the default stream (caches, allocator)
+                self._upload(scheduler._timesteps_host[0], draw=False)
+                for _ in range(warmup):
+                    self._body()
+        finally:
+            mv.dual_stream_eager = was_eager
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

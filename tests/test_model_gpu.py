@@ -472,9 +472,11 @@ def test_whole_denoising_step_at_cfg4_and_cfg5_size(name):
     these sizes (1288 TFLOP per step); what is asserted is size-independent:
     (1) the step replayed from the captured two-stream hipGraph == the step issued eagerly on one stream, BIT FOR BIT, from the
         same latents and RNG states (graph capture, routing thresholds, mask / PE tables and every kernel at these shapes);
-    (2) CFG-row independence: with the conditioning of row 0 copied into row 1 the two rows of every prediction agree to far
-        below the storage error (rows are separate images / token ranges of every kernel; hipBLASLt may pick position-dependent
-        split-K orders, hence a bound instead of equality);
+    (2) CFG-row independence: with the conditioning of row 0 copied into row 1 the two rows of every prediction agree -- bit for
+        bit at cfg4 size; at cfg5 size hipBLASLt's stream-K kernels accumulate the two rows' tiles in position-dependent orders
+        and ~60 layers decorrelate those last-bit differences up to the storage error of the format (1.3e-3 / 1.7e-3 observed in
+        fp16, like two runs with different GEMM solutions), hence a bound of a few storage errors instead of equality: a row
+        read from the wrong place is an O(1) error;
     (3) longitude rotation: with the seven WarpAttn blocks at their reference initialisation (zero output projections,
         src/modules/transformer.py:30-32, 55-57: exact identities) the panorama branch is the circularly padded UNet alone, and
         rolling the input latent along W rolls the prediction -- up to the 16-bit rounding of two different evaluations and the
@@ -537,7 +539,7 @@ def test_whole_denoising_step_at_cfg4_and_cfg5_size(name):
         for prm in (blk.transformer.attn1.to_out.weight, blk.transformer.attn1.to_out.bias, blk.transformer.ff.net[2].weight, blk.transformer.ff.net[2].bias):
             prm.zero_()                    # (in place ON the parameter: bumps its version, the packed-weight caches rebuild)
     W = w["pano_hw"][1]
-    shift = W // 4 + 3
+    shift = (W // 32 + 1) * 8              # a multiple of 8: the three stride-2 downsamplers sample on a grid of period 8 latent columns
     _, pn_a = mv(**kw, **einp)
     pn_a = pn_a.clone()
     rolled = dict(einp, pano_latent=torch.roll(einp["pano_latent"], shift, dims=-1).contiguous())
@@ -551,7 +553,7 @@ def test_whole_denoising_step_at_cfg4_and_cfg5_size(name):
     half = dt == torch.float16
     assert errs["finite"] and errs["graph_bit_identical"], errs
     assert errs["step_moved_the_latent"] > 3e-3, errs
-    assert errs["cfg_rows_pano"] < (1e-3 if half else 6e-3) and errs["cfg_rows_pers"] < (1e-3 if half else 6e-3), errs
+    assert errs["cfg_rows_pano"] < (4e-3 if half else 2.5e-2) and errs["cfg_rows_pers"] < (4e-3 if half else 2.5e-2), errs
     assert errs["rotation_rel"] < (1.5e-2 if half else 4e-2), errs
     assert errs["rotation_worst_column_over_median"] < 2.5 and errs["rotation_moved_the_prediction"] > 0.5, errs
 
