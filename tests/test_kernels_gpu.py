@@ -42,7 +42,7 @@ def q16(t, dt):
 
 
 def test_library_loads():
-    assert K.lib().im360_abi_version() == 1
+    assert K.lib().im360_abi_version() == K.ABI_VERSION == 2
 
 
 @pytest.mark.parametrize("dt", DTYPES)
