@@ -239,7 +239,7 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: PLUMBING CHECK on CPU tensors (tests/test_dist_cpu.py): the rank bookkeeping, sharding, collectives and the JSON "
                          "line of this script with whatever `imagine360_amd.kernels` the caller installed; never a benchmark number")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_hbm_traffic.json"),
                     help="rocprofv3 PMC summary (tools/hbm_traffic.sh) the roofline block quotes HBM traffic from")
     args = ap.parse_args(argv)
     if args.no_cpu_baseline:
