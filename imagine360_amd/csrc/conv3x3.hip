@@ -161,7 +161,17 @@ __device__ __forceinline__ void epi_ln_row_stats(const ConvParams& p, long m0, i
 // level-0 out-projection + residual -- that GEMM moves 1.26 GB in 0.31 ms, it is at the HBM rate, not waiting for a latency.  Both
 // dropped: RESM 1 requests per block, half before and half behind its register -> LDS pass.
 // Same arithmetic in all three: identical values (RESM 2 keeps the sign of a zero that x + 0 would clear).
-template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2, int RESM = 0>
+// ZACC (the four-wave tile, conv3x3_g4.hip): the accumulators live in AGPRs (asm constraint "a") and the next tile accumulates into
+// them from its first MFMA; once a pixel block's values have left the registers its TN accumulators are cleared by one MFMA each with
+// zero operands and C = 0 (the matrix pipe is idle during the epilogue; 256 v_accvgpr_write would cost 1000 issue cycles per tile).
+template <typename T> __device__ __forceinline__ void zero_acc_mfma(f32x16& d) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    // (s_nop 11: the wait states an 8-pass MFMA result needs before anything but an accumulating MFMA may touch it -- hipcc does not know
+    //  what the statement is and may copy / spill the output right behind it; s_nop 1 in front: VALU write of z -> MFMA operand)
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0\n\ts_nop 11" : "=a"(d) : "v"(z));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0\n\ts_nop 11" : "=a"(d) : "v"(z));
+}
+template <typename T, int NT, int TM, int TN, int EPI, bool COUT8 = false, bool UP2 = false, bool GNS = false, int WN_ = 2, int RESM = 0, bool ZACC = false>
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)[TN][TM], char* lds, long m0, int n0,
                                               int wm, int wn, int wid_s, int lane, const float* cvec = nullptr, int bn = 0,
                                               const float* ln_pre = nullptr) {
@@ -175,7 +185,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
     // and 16-byte aligned; the 16-byte piece index is XORed with row bits and the two 8-byte halves of a piece are
     // swapped on odd row octets, which makes the fragment-side 8-byte writes of 16 consecutive pixels hit 16
     // different bank pairs (checked exhaustively for 320- and 128-byte rows).  The row-major side reads whole pieces.
-    auto piece_xor = [](int row, int rowb) { return rowb == 128 ? (row & 7) : ((row >> 1) & 3); };
+    // (256-byte rows -- the four-wave tile's plain epilogue -- take the 128-byte pattern: a row is then a whole number of the
+    //  stores' 128-byte bank windows, and the XOR stays inside a group of eight pieces)
+    // (64-byte rows -- the GEGLU epilogue of the 256 x 128 tile, TN = 2: four pieces per row, two rows per bank window)
+    auto piece_xor = [](int row, int rowb) { return (rowb == 320 || rowb == 64) ? ((row >> 1) & 3) : (row & 7); };
     if constexpr (EPI == 1 || EPI == 4) {
         // GEGLU epilogue (token-major linear only): the packed weight rows alternate 32 value rows / 32 gate rows of the
         // same output channels, so accumulators (2i, 2i+1) hold value and gate of one channel in the same lane and
@@ -183,7 +196,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         static_assert(TN % 2 == 0, "value / gate blocks come in pairs");
         constexpr int ROWB = (TN / 2) * 64;
         constexpr int PIECES = ROWB / 16;
-        static_assert(ROWB == 128, "swizzle pattern");
+        static_assert(ROWB == 128 || ROWB == 64, "swizzle pattern");
         const int I = p.Cout / 2;
         const int ow0 = nw0 / 2;                  // first output channel of this wave
         char* wlds = lds + wid_s * (32 * ROWB);
@@ -221,22 +234,23 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 epi_ln_row_stats<TM>(p, m0, wm, col, ln_mu, ln_rs);
             }
         }
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
+        static_for<TM>([&](auto bcc) {
+            constexpr int b = decltype(bcc)::value;
             const long mb = m0 + wm * (TM * 32) + b * 32;
             f32x2 MU = {0.f, 0.f}, RS = {1.f, 1.f};
             if constexpr (EPI == 4) {
                 MU = f32x2{ln_mu[b], ln_mu[b]};
                 RS = f32x2{ln_rs[b], ln_rs[b]};
             }
-#pragma unroll
-            for (int i = 0; i < TN / 2; ++i)
+            static_for<TN / 2>([&](auto icc) {
+                constexpr int i = decltype(icc)::value;
+                const f32x16 av = acc[2 * i][b], ag = acc[2 * i + 1][b];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // (the unfused path rounds the projection to 16 bits before the activation; this one does not --
                     //  one rounding less on the way to the fp32 oracle)
-                    f32x2 v01 = {acc[2 * i][b][4 * g], acc[2 * i][b][4 * g + 1]}, v23 = {acc[2 * i][b][4 * g + 2], acc[2 * i][b][4 * g + 3]};
-                    f32x2 t01 = {acc[2 * i + 1][b][4 * g], acc[2 * i + 1][b][4 * g + 1]}, t23 = {acc[2 * i + 1][b][4 * g + 2], acc[2 * i + 1][b][4 * g + 3]};
+                    f32x2 v01 = {av[4 * g], av[4 * g + 1]}, v23 = {av[4 * g + 2], av[4 * g + 3]};
+                    f32x2 t01 = {ag[4 * g], ag[4 * g + 1]}, t23 = {ag[4 * g + 2], ag[4 * g + 3]};
                     if constexpr (EPI == 4) {
                         const int rv = nw0 - n0 + (2 * i) * 32 + 8 * g + 4 * hi, rg = rv + 32;      // packed rows, relative to the tile
                         const f32x4 k1v = *(const f32x4*)(cvec + rv), k2v = *(const f32x4*)(cvec + bn + rv);
@@ -258,6 +272,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     o.y = pack2<T>(v23.x, v23.y);
                     *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                 }
+            });
+            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T>(acc[decltype(ac)::value][b]); });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -274,7 +290,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-        }
+        });
         return;
     } else {
     // ---- epilogue.  Lane (pixel = col, hi) holds 4 consecutive couts per register group, i.e. stored directly every
@@ -285,7 +301,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
     if (COUT8 || (p.Cout & 7) == 0) {
         constexpr int ROWB = TN * 64;
         constexpr int PIECES = ROWB / 16;
-        static_assert(ROWB == 128 || ROWB == 320, "swizzle pattern");
+        static_assert(ROWB == 128 || ROWB == 256 || ROWB == 320, "swizzle pattern");
         static_assert((32 * PIECES) % 64 == 0, "store rounds cover the block exactly");
         static_assert(!GNS || (!UP2 && EPI != 3), "GroupNorm statistics: plain conv / linear epilogues");
         // GNS: every lane keeps ONE 16-byte piece (8 channels) through all store rounds -- RPR whole rows per round on
@@ -338,8 +354,11 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
         static_for<TM>([&](auto bcc) {
             constexpr int b = decltype(bcc)::value;
             const long mb = m0 + wm * (TM * 32) + b * 32;           // first pixel of the block (wave-uniform)
-            if (mb >= p.M) return;
-            const int rows = p.M - mb < 32 ? (int)(p.M - mb) : 32;  // valid rows of the block
+            // (ZACC = the four-wave tile: M % 256 == 0, every block is whole -- and no control flow splits the accumulators' live ranges)
+            if constexpr (!ZACC) {
+                if (mb >= p.M) return;
+            }
+            const int rows = ZACC ? 32 : (p.M - mb < 32 ? (int)(p.M - mb) : 32);  // valid rows of the block
             u32x4 (&rv)[NIT] = rvs[0];
             const char* rbase = res ? (const char*)(res + mb * p.Cout) : zsrc;
             char* ybase = (char*)(yg + mb * p.Cout);
@@ -364,8 +383,9 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
             };
             load_res(0, NIT1);
             __builtin_amdgcn_sched_barrier(0);    // (hipcc would hoist every load of the block up here and spill)
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
+            static_for<TN>([&](auto acc_c) {
+                constexpr int a = decltype(acc_c)::value;
+                const f32x16 at = acc[a][b];
                 if constexpr (EPI == 3) {
                     // the column vectors come from LDS (staged once per tile by the kernel: from global memory the forty
                     // dependent load rounds of a block cost more than the LayerNorm pass this epilogue replaces)
@@ -375,7 +395,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                         const f32x4 k1 = *(const f32x4*)(cvec + cr), k2 = *(const f32x4*)(cvec + bn + cr);
                         float f[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) f[j] = (acc[a][b][4 * g + j] - ln_mu * k1[j]) * ln_rstd + k2[j];
+                        for (int j = 0; j < 4; ++j) f[j] = (at[4 * g + j] - ln_mu * k1[j]) * ln_rstd + k2[j];
                         uint2 o;
                         o.x = pack2<T>(f[0], f[1]);
                         o.y = pack2<T>(f[2], f[3]);
@@ -402,7 +422,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 for (int g = 0; g < 4; ++g) {
                     float f[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = acc[a][b][4 * g + j];
+                    for (int j = 0; j < 4; ++j) f[j] = at[4 * g + j];
                     f[0] += unpack_lo<T>(wb[g].x); f[1] += unpack_hi<T>(wb[g].x); f[2] += unpack_lo<T>(wb[g].y); f[3] += unpack_hi<T>(wb[g].y);
                     if constexpr (EPI == 0) {
                         f[0] += unpack_lo<T>(wt[g].x); f[1] += unpack_hi<T>(wt[g].x); f[2] += unpack_lo<T>(wt[g].y); f[3] += unpack_hi<T>(wt[g].y);
@@ -414,7 +434,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
+            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T>(acc[decltype(ac)::value][b]); });
             load_res(NIT1, NIT);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1545,6 +1566,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
 }
 
+// ---- the four-wave, register-staged tile for the token-major GEMMs (round 6)
+#include "conv3x3_g4.hip"
+
 // ---- ablation-only kernels (`make ablate`, -DIM360_ABLATE): gemm_a3_kernel (two activation stages in flight, knob conv_ring 10) and
 //      conv_halo_kernel (halo-patch 3 x 3 convolution, knob conv_halo) with its launcher -- measured, slower, not shipped; they live
 //      in conv3x3_ablate.hip and see this file's ConvParams / tile_epilogue / helpers
@@ -1947,6 +1971,8 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
         if (dtype == 1) return launch_conv_t<_Float16, 2, 2, 2, 4, 1>(p, s);
     }
 #endif
+    if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)       // the four-wave register-staged tile
+        return dtype == 0 ? launch_g4_t<__bf16, 1>(p, s) : launch_g4_t<_Float16, 1>(p, s);
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
         const int v = knob(KNOB_CONV_RING) == 5 ? 1 : (knob(KNOB_CONV_RING) == 7 ? 6 : knob(KNOB_CONV_RING));      // (5 / 7: the ring kernel for the convolutions too)
         if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);
@@ -1992,7 +2018,9 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "linear_fwd: null pointer");
     IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_fwd: K=%ld must be a positive multiple of 32", (long)K);
-    IM360_CHECK_ARG(N > 0 && (N % 320) == 0, "linear_fwd: N=%ld must be a positive multiple of 320", (long)N);
+    // the four-wave register-staged tile (conv3x3_g4.hip; knob conv_ring 12): 256-column tiles
+    const bool g4_ok = knob(KNOB_CONV_RING) == 12 && !rowstats && !gn_partial && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (N % 256) == 0 && (M / 256) * (N / 256) >= 256;
+    IM360_CHECK_ARG(N > 0 && ((N % 320) == 0 || g4_ok), "linear_fwd: N=%ld must be a positive multiple of 320", (long)N);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                     ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_fwd: misaligned pointer");
     IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_fwd: dtype %d unsupported", dtype);
@@ -2006,6 +2034,7 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
     const int kr = knob(KNOB_CONV_RING);
+    if (g4_ok) return dtype == 0 ? launch_g4_t<__bf16, 2>(p, s) : launch_g4_t<_Float16, 2>(p, s);
     const int v = kr == 5 ? 1 : (kr == 7 ? 6 : kr);
     if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1);
     return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);
@@ -2063,6 +2092,8 @@ extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const 
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
+    if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)
+        return dtype == 0 ? launch_g4_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4_t<_Float16, 4>(p, (hipStream_t)stream);
     const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10 || knob(KNOB_CONV_RING) == 11) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);
 }

@@ -82,7 +82,7 @@ def cfg_half_inputs(inputs, half):
 def exchange_cfg_halves(pred, pair_group):
     """Both halves' predictions of the same frames, [uncond, text] along dim 0, on both ranks of ``pair_group``
     (= [rank of half 0, rank of half 1]): one small all-gather per branch and step."""
-    parts = [torch.empty_like(pred) for _ in range(2)]
+    parts = [torch.empty_like(pred) for _ in range(dist.get_world_size(pair_group))]      # (2; 1 in the single-GPU RCCL test)
     dist.all_gather(parts, pred.contiguous(), group=pair_group)
     return torch.cat(parts)
 
@@ -102,27 +102,31 @@ def cfg_frame_layout(frames, world=None, rank=None, boundary="module"):
     return my_half, FrameShard(frames, group=groups[my_half], rank=rank % half, world=half, boundary=boundary), pairs[rank % half]
 
 
-def frame_shard_pair(total_frames, group=None, boundary="module"):
+def frame_shard_pair(total_frames, group=None, boundary="module", force_collectives=False):
     """(shard, pano_shard): two FrameShards over the ranks of ``group`` -- the second on a NEW process group of the same ranks
     (a second RCCL communicator) for the panorama UNet (``MultiViewBaseModel.set_frame_shard(shard, pano_shard)``).  Collective:
     every rank of ``group`` has to call it (``dist.new_group``)."""
     ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
     second = dist.new_group(ranks=ranks)
     world, rank = len(ranks), ranks.index(dist.get_rank())
-    return (FrameShard(total_frames, group=group, rank=rank, world=world, boundary=boundary),
-            FrameShard(total_frames, group=second, rank=rank, world=world, boundary=boundary))
+    return (FrameShard(total_frames, group=group, rank=rank, world=world, boundary=boundary, force_collectives=force_collectives),
+            FrameShard(total_frames, group=second, rank=rank, world=world, boundary=boundary, force_collectives=force_collectives))
 
 
 class FrameShard:
     """Contiguous frame chunks across the ranks of ``group`` (frames % world == 0).  ``boundary``: where the motion
     modules exchange tokens -- "module" (default: one all-to-all behind the module's GroupNorm, one in front of its
     residual add; TemporalTransformer3DModel._forward_pixel_sharded) or "attention" (around every temporal attention;
-    VersatileAttention.forward)."""
+    VersatileAttention.forward).  ``force_collectives``: a shard of ONE rank normally short-circuits every exchange; with the flag it
+    packs, calls the collective and unpacks like any other -- how the single-GPU test pushes the whole exchange path (pack kernel ->
+    ``all_to_all_single`` -> temporal kernel on the receive buffer -> return trip, ``all_gather``) through RCCL at world size 1,
+    eagerly and captured in a hipGraph (tests/test_dist_gpu.py)."""
 
-    def __init__(self, total_frames, group=None, rank=None, world=None, boundary="module"):
+    def __init__(self, total_frames, group=None, rank=None, world=None, boundary="module", force_collectives=False):
         if boundary not in ("module", "attention"):
             raise ValueError(f"FrameShard boundary {boundary!r}: 'module' or 'attention'")
         self.boundary = boundary
+        self.force_collectives = bool(force_collectives)
         self.group = group
         self.world = dist.get_world_size(group) if world is None else world
         self.rank = dist.get_rank(group) if rank is None else rank
@@ -138,7 +142,7 @@ class FrameShard:
 
     def gather_frames(self, x, dim):
         """All-gather the frame chunks back along ``dim`` (latent boundary)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return x
         parts = [torch.empty_like(x) for _ in range(self.world)]
         dist.all_gather(parts, x.contiguous(), group=self.group)
@@ -178,7 +182,7 @@ class FrameShard:
         from . import kernels
         b, fl, p, c = x.shape
         w, pp = self.world, self.pixels_per_rank(p)
-        if w == 1:
+        if w == 1 and not self.force_collectives:
             return x.permute(1, 0, 2, 3).reshape(fl * b * p, c).contiguous()
         send = kernels.shard_pack(x.contiguous(), self._buf("f2p_send", (w, fl, b, pp, c), x), b, fl, p, w, pp)
         return self.exchange(send, "f2p_recv").reshape(w * fl * b * pp, c)
@@ -194,7 +198,7 @@ class FrameShard:
         from . import kernels
         c = y.shape[-1]
         w, fl, pp = self.world, self.local, self.pixels_per_rank(pixels)
-        if w == 1:
+        if w == 1 and not self.force_collectives:
             return y.reshape(fl, batch, pixels, c).permute(1, 0, 2, 3).contiguous()
         recv = self.exchange(y.reshape(w, fl, batch, pp, c), "p2f_recv")
         out = torch.empty((batch, fl, pixels, c), dtype=y.dtype, device=y.device)

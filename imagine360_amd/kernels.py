@@ -517,7 +517,7 @@ def linear(x, w_packed, n, bias=None, res=None, row_stats=False, gn_hw=None):
     _dev(x, w_packed, bias, res)
     k = x.shape[-1]
     m = x.numel() // k
-    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[1] == 1 and n % 320 == 0
+    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[1] == 1 and (n % 320 == 0 or n % 256 == 0)      # (256: the four-wave tile, knob conv_ring 12)
     y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
     assert res is None or (res.is_contiguous() and res.numel() == y.numel() and res.dtype == x.dtype)
     st = torch.empty((m, n // ROW_SLICE, 2), dtype=torch.float32, device=x.device) if row_stats else None

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fn, ret):
+def _worker(rank, world, port, fn, ret, backend="gloo"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.dirname(here)):
@@ -30,18 +30,18 @@ def _worker(rank, world, port, fn, ret):
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
     finally:
         dist.destroy_process_group()
 
 
-def _run(fn, world=2):
+def _run(fn, world=2, backend="gloo"):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -144,3 +144,96 @@ def test_frame_sharded_whole_forward_at_cfg4_size_matches_unsharded():
         assert out[r][4] and out[r][3] == [2, 4, 24, 64, 128], out[r]
         assert out[r][0] < 6e-3 and out[r][1] < 6e-3 and out[r][2] < 6e-3 and out[r][7] < 1.2e-2, out[r]
         assert out[r][5] == 64 and out[r][6] == expect_bytes, (out[r], expect_bytes)
+
+
+# ---- RCCL on the one GPU of the test box: backend "nccl" (= RCCL on ROCm) at world size 1 with FrameShard's
+#      single-rank shortcuts switched off, so that pack kernel -> all_to_all_single -> temporal kernel on the receive buffer -> return
+#      trip, all_gather of frames and the CFG pair exchange go through RCCL device buffers -- eagerly AND captured in a hipGraph, and
+#      with two communicators progressing on two streams inside one captured graph (the --dual-stream-shard layout).
+def _rccl_job(rank, world):
+    from imagine360_amd import kernels as K
+    from imagine360_amd.dist import FrameShard, exchange_cfg_halves, frame_shard_pair
+    assert dist.get_backend() == "nccl"
+    dt, dev = torch.bfloat16, torch.device("cuda", 0)
+    b, f, p, heads, d = 2, 16, 203, 8, 40
+    c = heads * d
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(b, f, p, 3 * c, generator=g).to(dev, dt)
+    qkv2 = torch.randn(b, f, p, 3 * c, generator=g).to(dev, dt)
+    full = K.temporal_attention(qkv.reshape(-1, 3 * c), b, f, p, heads).reshape(b, f, p, c)
+    full2 = K.temporal_attention(qkv2.reshape(-1, 3 * c), b, f, p, heads).reshape(b, f, p, c)
+    out = {}
+
+    def round_trip(sh, x):
+        q = sh.frames_to_pixels(x)
+        a = K.temporal_attention(q, b, sh.total, sh.pixels_per_rank(p), heads, frame_major=True, out=sh.pixel_result_buffer(x, b, p, c))
+        return sh.pixels_to_frames(a, b, p)
+
+    # 1. eager, through RCCL
+    sh = FrameShard(f, force_collectives=True)
+    n_exch = []
+    orig = sh.exchange
+    sh.exchange = lambda send, tag: (n_exch.append(tag), orig(send, tag))[1]
+    out["eager"] = bool(torch.equal(round_trip(sh, qkv), full))
+    out["exchanges"] = list(n_exch)
+    out["gather"] = bool(torch.equal(sh.gather_frames(full.contiguous(), 1), full))
+    pair = dist.new_group([0])
+    out["cfg_pair"] = bool(torch.equal(exchange_cfg_halves(full, pair), full))
+    torch.cuda.synchronize()
+
+    # 2. the same exchange captured in a hipGraph and replayed on new data
+    static_in = qkv.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        round_trip(sh, static_in)                      # warm-up on the capture stream (buffers, communicator)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_out = round_trip(sh, static_in)
+    res = []
+    for src, want in ((qkv2, full2), (qkv, full)):
+        static_in.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        res.append(bool(torch.equal(static_out, want)))
+    out["graph"] = res
+
+    # 3. two communicators on two streams inside ONE captured graph
+    sh_a, sh_b = frame_shard_pair(f, force_collectives=True)
+    in_a, in_b = qkv.clone(), qkv2.clone()
+    s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):                                 # warm-up, eagerly on the two streams
+        s_main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_main):
+            s_side.wait_stream(s_main)
+            with torch.cuda.stream(s_side):
+                wb = round_trip(sh_b, in_b)
+            wa = round_trip(sh_a, in_a)
+            s_main.wait_stream(s_side)
+        torch.cuda.current_stream().wait_stream(s_main)
+        torch.cuda.synchronize()
+    out["two_comm_eager"] = [bool(torch.equal(wa, full)), bool(torch.equal(wb, full2))]
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=s_main):
+        s_side.wait_stream(s_main)
+        with torch.cuda.stream(s_side):
+            out_b = round_trip(sh_b, in_b)
+        out_a = round_trip(sh_a, in_a)
+        s_main.wait_stream(s_side)
+    in_a.copy_(qkv2)
+    in_b.copy_(qkv)
+    graph2.replay()
+    torch.cuda.synchronize()
+    out["two_comm_graph"] = [bool(torch.equal(out_a, full2)), bool(torch.equal(out_b, full))]
+    return out
+
+
+def test_exchange_path_through_rccl_at_world_size_one_eager_and_captured():
+    out = _run(_rccl_job, world=1, backend="nccl")[0]
+    print("RCCL world size 1:", out)
+    assert out["eager"] and out["gather"] and out["cfg_pair"], out
+    assert out["exchanges"] == ["f2p_recv", "p2f_recv"], out            # both trips went through all_to_all_single
+    assert out["graph"] == [True, True], out
+    assert out["two_comm_eager"] == [True, True] and out["two_comm_graph"] == [True, True], out
