@@ -20,14 +20,14 @@ extern "C" __attribute__((visibility("hidden"))) void im360_set_error(const char
     va_end(ap);
 }
 
-extern "C" const char* im360_last_error(void) { return g_err; }
+extern "C" __attribute__((visibility("default"))) const char* im360_last_error(void) { return g_err; }
 
 // 2 (round 5): im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer, im360_linear_ln_fwd's table rows include c2
 // (round 4 changed both without bumping the number; callers built against version 1 must not load this library)
-extern "C" int im360_abi_version(void) { return 2; }
+extern "C" __attribute__((visibility("default"))) int im360_abi_version(void) { return 2; }
 
 // bit 0: built with -DIM360_ABLATE (`make ablate`): the rejected A/B variants and the ablation kernels are in the library
-extern "C" int im360_build_flags(void) {
+extern "C" __attribute__((visibility("default"))) int im360_build_flags(void) {
 #ifdef IM360_ABLATE
     return 1;
 #else
@@ -43,7 +43,7 @@ std::vector<Slot> g_used, g_free;
 unsigned g_mask = 0;
 }  // namespace
 
-extern "C" void im360_prof_enable(unsigned mask) {
+extern "C" __attribute__((visibility("default"))) void im360_prof_enable(unsigned mask) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_mask = mask;
 }
@@ -60,19 +60,19 @@ ProfScope::ProfScope(int kind, void* stream) : slot_(-1), stream_(stream) {
         if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
     }
     s.kind = kind;
-    hipEventRecord(s.a, (hipStream_t)stream);
+    (void)hipEventRecord(s.a, (hipStream_t)stream);
     g_used.push_back(s);
     slot_ = (int)g_used.size() - 1;
 }
 ProfScope::~ProfScope() {
     if (slot_ < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    hipEventRecord(g_used[slot_].b, (hipStream_t)stream_);
+    (void)hipEventRecord(g_used[slot_].b, (hipStream_t)stream_);
 }
 }  // namespace im360
 
 // Sums the elapsed time of every recorded launch of `kind` since the last collect; blocks on the events.
-extern "C" int im360_prof_collect(int kind, double* total_ms, long* launches) {
+extern "C" __attribute__((visibility("default"))) int im360_prof_collect(int kind, double* total_ms, long* launches) {
     std::lock_guard<std::mutex> lk(g_mu);
     double tot = 0.0;
     long n = 0;
@@ -119,7 +119,7 @@ Knobs g_knobs;
 
 int im360::knob(int k) { return (k >= 0 && k < im360::KNOB_COUNT) ? g_knobs.v[k].load(std::memory_order_relaxed) : 0; }
 
-extern "C" int im360_tuning_set(int knob, int value) {
+extern "C" __attribute__((visibility("default"))) int im360_tuning_set(int knob, int value) {
     if (knob < 0 || knob >= im360::KNOB_COUNT) {
         im360_set_error("tuning_set: unknown knob %d", knob);
         return -1;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
     constexpr int SNT = HG ? 64 : NW * 64;     // threads that stage one K / V tile together
     static_assert(!DUAL || (QB == 1 && !HAS_BIAS), "the two-set kernel is the plain one-block-per-wave kernel run twice");
     static_assert(!BF || HAS_BIAS, "bias fragments need a bias");
-    constexpr int NT = NW * 64;
+    [[maybe_unused]] constexpr int NT = NW * 64;
     constexpr int KP = D + 8;          // K tile pitch (elements): 16-B slots rotate by an odd count per row
     constexpr int VP = D == 64 ? 96 : 32;   // V tile pitch: 192-B / 64-B rows -> rows r..r+3 hit 4 distinct 64-B bank windows
     constexpr int DC = D / 16;         // k-steps of the QK^T contraction
@@ -1001,7 +1001,7 @@ static int launch_attn(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace im360
 
-extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias, void* out,
+extern "C" __attribute__((visibility("default"))) int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias, void* out,
                               int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t D,
                               int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
@@ -1048,7 +1048,7 @@ extern "C" int im360_attn_fwd(const void* q, const void* k, const void* v, const
 
 // Two key / value sets for the same queries in ONE launch: out = out_scale * softmax(q k^T scale) v + out_scale2 *
 // softmax(q k2^T scale) v2 (head dim 64, no bias).  Strides as in im360_attn_fwd.
-extern "C" int im360_attn_fwd2(const void* q, const void* k, const void* v, const void* k2, const void* v2, void* out,
+extern "C" __attribute__((visibility("default"))) int im360_attn_fwd2(const void* q, const void* k, const void* v, const void* k2, const void* v2, void* out,
                                int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t Nk2, int64_t D,
                                int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs,
                                int64_t k2_bs, int64_t k2_rs, int64_t v2_bs, int64_t v2_rs, int64_t o_bs, int64_t o_rs,

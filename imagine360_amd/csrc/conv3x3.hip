@@ -1858,7 +1858,7 @@ __global__ void pack_conv_weight_kernel(const T* __restrict__ w, T* __restrict__
 // epilogue (gn_partial: fp32 [N * S][2][Cout]), or 0 when it cannot: needs the 256 x 320 tile (Cout % 320 == 0, Cin % 64 == 0,
 // at least 512 tiles) and images that are whole numbers of 256-pixel tiles.  For a linear, pass the [N, Hout, Wout] image
 // shape of its token rows and ntaps = 1.
-extern "C" int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps) {
+extern "C" __attribute__((visibility("default"))) int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps) {
     using namespace im360;
     const int64_t hw = Hout * Wout, M = N * hw;
     if (N <= 0 || hw <= 0 || (hw % 256) != 0 || (Cout % 320) != 0 || (Cin % 64) != 0 || (ntaps != 1 && ntaps != 9)) return 0;
@@ -1866,7 +1866,7 @@ extern "C" int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, in
     return hw / 256;
 }
 
-extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
+extern "C" __attribute__((visibility("default"))) int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
                               const void* res, void* y,
                               int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
                               int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
@@ -1905,7 +1905,7 @@ extern "C" int im360_conv_fwd(const void* x, const void* w_packed, const void* b
 // nearest-x2 upsample + conv3x3 (pad 1) as four 2 x 2 convolutions of the low-resolution input, one per output parity:
 // x [N, Hin, Win, Cin] -> y [N, 2 Hin, 2 Win, Cout]; w4 = four packed 4-tap weights [4][CoutPad][4][Cin] in parity order
 // (py, px) = (0,0) (0,1) (1,0) (1,1), each the sum of the 3 x 3 taps that land on the same source pixel.
-extern "C" int im360_conv_up2_fwd(const void* x, const void* w4, const void* bias, void* y, int64_t N, int64_t Hin,
+extern "C" __attribute__((visibility("default"))) int im360_conv_up2_fwd(const void* x, const void* w4, const void* bias, void* y, int64_t N, int64_t Hin,
                                   int64_t Win, int64_t Cin, int64_t Cout, int64_t wrap, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && w4 && y, "conv_up2_fwd: null pointer");
@@ -1949,7 +1949,7 @@ extern "C" int im360_conv_up2_fwd(const void* x, const void* w4, const void* bia
     return IM360_OK;
 }
 
-extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
+extern "C" __attribute__((visibility("default"))) int im360_linear_geglu(const void* x, const void* w_packed, const void* bias_packed, void* y,
                                   int64_t M, int64_t K, int64_t I, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "linear_geglu: null pointer");
@@ -1973,6 +1973,8 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
 #endif
     if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)       // the four-wave register-staged tile
         return dtype == 0 ? launch_g4_t<__bf16, 1>(p, s) : launch_g4_t<_Float16, 1>(p, s);
+    if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)       // the same loop, two workgroups per CU (256 x 128 tiles)
+        return dtype == 0 ? launch_g4b_t<__bf16, 1>(p, s) : launch_g4b_t<_Float16, 1>(p, s);
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
         const int v = knob(KNOB_CONV_RING) == 5 ? 1 : (knob(KNOB_CONV_RING) == 7 ? 6 : knob(KNOB_CONV_RING));      // (5 / 7: the ring kernel for the convolutions too)
         if (dtype == 0) return launch_ring_t<__bf16, 4, 1, true>(p, s, v);
@@ -1987,7 +1989,7 @@ extern "C" int im360_linear_geglu(const void* x, const void* w_packed, const voi
 // 1x1 convolution of the channel concatenation [xa | xb] that is never materialised (the skip connections of the decoder:
 // src/models/MVGenModel.py:407, 415, 431, 437 concatenate, animatediff/models/resnet.py:248-251 runs conv_shortcut on the
 // result): xa [N, H, W, C1], xb [N, H, W, C2], w_packed [CoutPad][1][C1 + C2] -> y [N, H, W, Cout] (+ bias, + res).
-extern "C" int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void* w_packed, const void* bias, const void* res,
+extern "C" __attribute__((visibility("default"))) int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void* w_packed, const void* bias, const void* res,
                                      void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t Cout,
                                      int dtype, void* stream) {
     using namespace im360;
@@ -2013,7 +2015,7 @@ extern "C" int im360_conv1x1_cat_fwd(const void* xa, const void* xb, const void*
 // 160-column slice -- what a following LayerNorm needs, so that the consumer can fold the normalisation into its GEMM
 // (im360_linear_ln_fwd / im360_linear_geglu_ln) and the LayerNorm pass over the activations disappears.
 // Replaces: nn.Linear + residual add feeding nn.LayerNorm, animatediff/models/attention.py:461-508, motion_module.py:230-258.
-extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y,
+extern "C" __attribute__((visibility("default"))) int im360_linear_fwd(const void* x, const void* w_packed, const void* bias, const void* res, void* y,
                                 void* rowstats, int64_t M, int64_t K, int64_t N, int dtype, void* stream, void* gn_partial) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "linear_fwd: null pointer");
@@ -2046,7 +2048,7 @@ extern "C" int im360_linear_fwd(const void* x, const void* w_packed, const void*
 // c1[n] = sum_k w'[n][k] (of the ROUNDED 16-bit w'), c2 = W beta + bias, tab (optional, fp32 [tab_mod][N]) = c2 + e.g. the
 // motion module's frame positional encoding pushed through the projection (ABI version 2: the table rows INCLUDE c2).  All fp32 vectors.  N % 320 == 0, K % 32 == 0.
 // Replaces: nn.LayerNorm -> nn.Linear (to_q / fused qkv), animatediff/models/attention.py:470-488, motion_module.py:236-250.
-extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+extern "C" __attribute__((visibility("default"))) int im360_linear_ln_fwd(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
                                    int64_t rs_p, float eps, const void* tab, int64_t tab_div, int64_t tab_mod, void* y,
                                    int64_t M, int64_t K, int64_t N, int dtype, void* stream) {
     using namespace im360;
@@ -2074,7 +2076,7 @@ extern "C" int im360_linear_ln_fwd(const void* x, const void* w_packed, const vo
 // LayerNorm folded into the fused GEGLU projection (im360_linear_geglu with w_packed = pack_geglu(gamma (.) W) and the
 // fp32 vectors c1, c2 in the same interleaved row order): out = v * gelu(g), (v | g) = rstd * (x w^T - mu c1) + c2.
 // Replaces: nn.LayerNorm -> GEGLU, animatediff/models/attention.py:503-506, motion_module.py:255-257.
-extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
+extern "C" __attribute__((visibility("default"))) int im360_linear_geglu_ln(const void* x, const void* w_packed, const void* c1, const void* c2, const void* rowstats,
                                      int64_t rs_p, float eps, void* y, int64_t M, int64_t K, int64_t I, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && c1 && c2 && rowstats && y, "linear_geglu_ln: null pointer");
@@ -2094,11 +2096,13 @@ extern "C" int im360_linear_geglu_ln(const void* x, const void* w_packed, const 
     ProfScope prof(PROF_GEMM, stream);
     if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)
         return dtype == 0 ? launch_g4_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4_t<_Float16, 4>(p, (hipStream_t)stream);
+    if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)
+        return dtype == 0 ? launch_g4b_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4b_t<_Float16, 4>(p, (hipStream_t)stream);
     const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10 || knob(KNOB_CONV_RING) == 11) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);
 }
 
-extern "C" int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,
+extern "C" __attribute__((visibility("default"))) int im360_pack_conv_weight(const void* w, void* out, int64_t Cout, int64_t Cin, int64_t taps,
                                       int64_t CoutPad, int64_t CinPad, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(w && out, "pack_conv_weight: null pointer");

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int ROWB = BK * 2;                              // 128-byte rows: one line per row and stage
     constexpr int PANEL = 256 * ROWB;                         // 32 KB: the token rows, then the weight rows
-    constexpr int SLOT = 2 * PANEL;                           // 64 KB per stage
     constexpr int NP = 16;                                    // 16-byte pieces per lane and stage (8 token rows + 8 weight rows)
     constexpr bool LNF = EPI == 4;
     constexpr int EPI_OFF = 4 * PANEL;                        // the epilogue's staging rows: 32 KB beside the stage buffers
@@ -349,6 +348,244 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (blockIdx.x == 0 && wid_s == 0)
             for (int k = lane; k < 256; k += 64) ((uint32_t*)p.y)[k] = k < nstamp ? ((uint32_t*)(lds + STAMP_OFF))[k] : 0u;
     }
+}
+
+// ---- the same loop for TWO workgroups per CU (256 x 128 tile, 256 registers per wave): one workgroup's epilogue under the other's K loop
+// tools/g4_stamps.py on the 256 x 256 kernel above: its K loop runs at 2460 cycles per 2048-cycle stage, but the fused GEGLU epilogue
+// takes 13 400 cycles per tile -- as long as the five stages of a K = 320 tile -- with the matrix pipes idle, and a lone wave per SIMD
+// issues one vector instruction per 4 cycles whatever it is (two interleaved waves pair their 2-cycle instructions).  Here a
+// workgroup is 4 waves x 256 registers, wave = 128 tokens x 64 packed rows (8 accumulators = 128 AGPRs), and two workgroups share a
+// CU: while one converts and stores its tile the other one's MFMAs have the matrix pipe, and both waves of a SIMD feed the vector
+// unit.  57 KB of LDS per workgroup: ONE stage buffer (256 + 128 rows of 128 bytes) + 8 KB of epilogue staging + the column vectors.
+//   stage g:  chunks 0 - 2 read their successor's fragments from the buffer; barrier A (every wave holds chunk 3's fragments);
+//             chunk 3: per piece (wait, ds_write piece i of stage g + 1 from its register, request piece i of stage g + 2 into it);
+//             barrier B; read stage g + 1's first fragments.  One register set: a request has one stage time (2 x 1024 MFMA cycles
+//             with the other workgroup on the pipe) to arrive; what this wave's LDS round trip at the buffer turnover exposes, the
+//             other workgroup's waves fill.
+//   tile boundaries as above: the last stage requests nothing, the epilogue runs with an empty queue, the next tile's first stage
+//   (already in the buffer) requests its second stage up front.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_g4b_kernel(ConvParams p) {
+    constexpr int NT = 256, WN = 2, TM = 4, TN = 2;
+    constexpr int BM = 256, BN = 128, BK = 64;
+    constexpr int ROWB = BK * 2;
+    constexpr int PANEL_A = BM * ROWB, PANEL_W = BN * ROWB;   // 32 KB + 16 KB
+    constexpr int NPA = 8, NPW = 4, NP = NPA + NPW;           // 16-byte pieces per lane and stage
+    constexpr bool LNF = EPI == 4;
+    constexpr int EPI_OFF = PANEL_A + PANEL_W;
+    constexpr int EPI_BYTES = (NT / 64) * 32 * ((TN / 2) * 64);       // 8 KB
+    constexpr int CVB = LNF ? 2 * BN * 4 : 0;
+    constexpr int LDS_BYTES = EPI_OFF + EPI_BYTES + CVB;
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    float* const cvec = (float*)(lds + EPI_OFF + EPI_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hi = lane >> 5;
+    const int wm = wid_s / WN, wn = wid_s % WN;
+    const char* xg = (const char*)p.x;
+    const char* wg = (const char*)p.w;
+    const int Kb = p.Cin * 2;
+    const int nph = p.Cin / BK;                               // >= 2 (launcher)
+
+    const int per_xcd = gridDim.x / 8;
+    const int xg_n = 8 / p.ngroups, tn_g = p.tiles_n / p.ngroups;
+    const int grp = (blockIdx.x % 8) / xg_n;
+    const int ntiles = (int)(p.nblocks / p.ngroups);
+    const int tile_first = ((blockIdx.x % 8) % xg_n) * per_xcd + blockIdx.x / 8;
+    const int tile_step = xg_n * per_xcd;
+    if (tile_first >= ntiles) return;
+    const int my_tiles = (ntiles - tile_first + tile_step - 1) / tile_step;
+    auto tile_m0 = [&](int j) { return (long)((uint32_t)j / (uint32_t)tn_g) * BM; };
+    auto tile_n0 = [&](int j) { return (grp * tn_g + (int)((uint32_t)j % (uint32_t)tn_g)) * BN; };
+
+    const int r0 = tid >> 3, c8 = tid & 7;
+    const uint32_t lds_u32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t wr_off = (uint32_t)(r0 * ROWB + ((c8 ^ ((r0 >> 1) & 7)) << 4));
+    const uint32_t wrA = lds_u32 + wr_off, wrW = lds_u32 + PANEL_A + wr_off;
+    const uint32_t voff = (uint32_t)(r0 * Kb + c8 * 16);
+    const long pstep = 32L * Kb;
+    const int swz = (col >> 1) & 7;
+    uint32_t rdX[4], rdW[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t ko = (uint32_t)(((ks * 2 + hi) ^ swz) << 4);
+        rdX[ks] = lds_u32 + (wm * 128 + col) * ROWB + ko;
+        rdW[ks] = lds_u32 + PANEL_A + (wn * 64 + col) * ROWB + ko;
+    }
+
+    int ptile = tile_first, pk = 0, pleft = my_tiles;
+    const char* pA = xg + tile_m0(ptile) * Kb;
+    const char* pW = wg + (long)tile_n0(ptile) * Kb;
+    auto producer_advance = [&]() {
+        if (pk + 1 < nph) {
+            ++pk;
+            pA += ROWB;
+            pW += ROWB;
+        } else if (pleft > 1) {
+            --pleft;
+            pk = 0;
+            ptile += tile_step;
+            pA = xg + tile_m0(ptile) * Kb;
+            pW = wg + (long)tile_n0(ptile) * Kb;
+        }
+    };
+    u32x4 S[NP];
+    auto load_piece = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < NPA) g4::gload128(S[i], voff, pA + i * pstep);
+        else g4::gload128(S[i], voff, pW + (i - NPA) * pstep);
+    };
+    auto write_piece = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < NPA) g4::lds_write128<i * 4096>(wrA, S[i]);
+        else g4::lds_write128<(i - NPA) * 4096>(wrW, S[i]);
+    };
+    u32x4 F[2][6];                                            // [set][0..3] token blocks, [4..5] weight blocks
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) zero_acc_mfma<T>(acc[a][b]);
+    auto read_frag = [&](auto ksc, auto fsc, auto jc) {
+        constexpr int ks = decltype(ksc)::value, fs = decltype(fsc)::value, j = decltype(jc)::value;
+        if constexpr (j < 4) g4::lds_read128<j * 4096>(F[fs][j], rdX[ks]);
+        else g4::lds_read128<(j - 4) * 4096>(F[fs][j], rdW[ks]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+
+    // prologue: stage 0 in the buffer, nothing in flight (= what a tile's last stage leaves behind)
+    static_for<NP>([&](auto ic) { load_piece(ic); });
+    producer_advance();
+    g4::wait_vm<0>();
+    static_for<NP>([&](auto ic) { write_piece(ic); });
+    g4::wait_lgkm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    static_for<6>([&](auto jc) { read_frag(I0{}, I0{}, jc); });
+    g4::wait_lgkm<0>();
+
+    auto stage = [&](auto modec) {
+        constexpr int MODE = decltype(modec)::value;
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, fs = q & 1;
+            static_for<8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, a = j / 4, b = j % 4;
+                g4::mfma_acc<T>(acc[a][b], F[fs][4 + a], F[fs][b]);
+                if constexpr (q < 3 && j < 6) read_frag(std::integral_constant<int, q + 1>{}, std::integral_constant<int, fs ^ 1>{}, jc);
+                if constexpr (MODE == g4::FIRST && q == 0) {
+                    // the tile's second stage, requested up front (the previous tile's last stage requested nothing)
+                    if constexpr (j < 4) {
+                        load_piece(std::integral_constant<int, 2 * j>{});
+                        load_piece(std::integral_constant<int, 2 * j + 1>{});
+                    } else {
+                        load_piece(std::integral_constant<int, 4 + j>{});
+                        if constexpr (j == 7) producer_advance();
+                    }
+                }
+                if constexpr (q == 3) {
+                    // buffer turnover: piece i of stage g + 1 out of its register, piece i of stage g + 2 requested into it
+                    auto piece = [&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        g4::wait_vm<NP - 1 - i + (MODE == g4::LAST ? 0 : i)>();       // younger: the rest of stage g + 1's requests (+ this stage's i)
+                        write_piece(ic);
+                        if constexpr (MODE != g4::LAST) load_piece(ic);
+                    };
+                    if constexpr (j < 4) {
+                        piece(std::integral_constant<int, 2 * j>{});
+                        piece(std::integral_constant<int, 2 * j + 1>{});
+                    } else {
+                        piece(std::integral_constant<int, 4 + j>{});
+                    }
+                }
+            });
+            if constexpr (q < 2) {
+                g4::wait_lgkm<0>();
+            } else if constexpr (q == 2) {
+                g4::wait_lgkm<0>();                           // chunk 3's fragments are in registers:
+                asm volatile("s_barrier" ::: "memory");       // barrier A -- nobody reads the buffer any more
+            } else {
+                if constexpr (MODE != g4::LAST) producer_advance();
+                g4::wait_lgkm<0>();
+                asm volatile("s_barrier" ::: "memory");       // barrier B -- stage g + 1 is complete
+                static_for<6>([&](auto jc) { read_frag(I0{}, I0{}, jc); });
+                g4::wait_lgkm<0>();
+            }
+        });
+    };
+    using MFirst = std::integral_constant<int, g4::FIRST>;
+    using MMid = std::integral_constant<int, g4::MID>;
+    using MLast = std::integral_constant<int, g4::LAST>;
+
+    int ctile = tile_first;
+    for (int t = 0; t < my_tiles; ++t) {
+        stage(MFirst{});
+        for (int k = 2; k < nph; ++k) stage(MMid{});
+        stage(MLast{});
+        // ---- epilogue: empty queue, no register in flight; the accumulators are cleared by tile_epilogue (ZACC)
+        const long m0 = tile_m0(ctile);
+        const int n0 = tile_n0(ctile);
+        asm volatile("s_nop 15\n\ts_nop 15"
+                     : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3])
+                     :: "memory");
+        int lane_e = lane, wid_e = wid_s;
+        asm volatile("" : "+v"(lane_e), "+s"(wid_e));
+        const int col_e = lane_e & 31, wm_e = wid_e / WN, wn_e = wid_e % WN;
+        float ln_pre[2 * TM];
+        if constexpr (LNF) {
+            const int tid_e = wid_e * 64 + lane_e;
+            if (tid_e < BN / 2) {
+                const int v = tid_e / (BN / 4), idx = (tid_e % (BN / 4)) * 4;
+                *(f32x4*)(cvec + v * BN + idx) = *(const f32x4*)((v ? p.ln_c2 : p.ln_c1) + n0 + idx);
+            }
+            float mus[TM], rstds[TM];
+            epi_ln_row_stats<TM>(p, m0, wm_e, col_e, mus, rstds);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                ln_pre[b] = mus[b];
+                ln_pre[TM + b] = rstds[b];
+            }
+            __syncthreads();
+        }
+        tile_epilogue<T, NT, TM, TN, EPI, false, false, false, WN, 0, true>(p, acc, lds + EPI_OFF, m0, n0, wm_e, wn_e, wid_e, lane_e, cvec, BN, LNF ? ln_pre : nullptr);
+        ctile += tile_step;
+        // (the first fragments of the next tile, read behind barrier B above, need not live across the epilogue)
+        static_for<6>([&](auto jc) { read_frag(I0{}, I0{}, jc); });
+        g4::wait_lgkm<0>();
+    }
+}
+
+template <typename T, int EPI>
+static int launch_g4b_t(ConvParams p, hipStream_t stream) {
+    constexpr int BM = 256, BN = 128;
+    p.tiles_n = p.Cout / BN;
+    p.nblocks = ((p.M + BM - 1) / BM) * p.tiles_n;
+    if (p.nblocks > 0x7fffffffL || p.Cout % BN != 0 || p.Cin % 64 != 0 || p.Cin < 128 || p.M % BM != 0) {
+        im360_set_error("gemm_g4b: unsupported shape");
+        return IM360_ERR_ARG;
+    }
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n >= 8 ? n / 8 * 8 : 8;
+    }();
+    const long want = (p.nblocks + 7) / 8 * 8;
+    const unsigned grid = (unsigned)(want < 2L * ncu ? want : 2L * ncu);      // two workgroups per CU
+    {
+        const long wbytes = (long)p.tiles_n * BN * p.Cin * 2;
+        int ng = 1;
+        const int force = knob(KNOB_RING_GROUPS);
+        if (force > 0) {
+            if ((force == 2 || force == 4 || force == 8) && p.tiles_n % force == 0) ng = force;
+        } else {
+            while (ng < 8 && wbytes / ng > 3400000L && p.tiles_n % (2 * ng) == 0) ng *= 2;
+            if (wbytes / ng > 3400000L) ng = 1;
+        }
+        p.ngroups = grid >= 8u * ng ? ng : 1;
+    }
+    hipLaunchKernelGGL((gemm_g4b_kernel<T, EPI>), dim3(grid), dim3(256), 0, stream, p);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
 }
 
 template <typename T, int EPI>

@@ -320,7 +320,7 @@ __global__ void shard_pack_kernel(const uint4* __restrict__ src, uint4* __restri
 // Replaces: nothing in the reference (it is single-process); this is the pack / unpack of the frame-chunk sharding's
 // all-to-all around VersatileAttention (animatediff/models/motion_module.py:343-429), one launch instead of pad + permute +
 // contiguous copies, writing into caller-owned (pre-sized) buffers so the exchange can be captured in a hipGraph.
-extern "C" int im360_shard_pack(const void* src, void* dst, int64_t B, int64_t Fl, int64_t P, int64_t C, int64_t W,
+extern "C" __attribute__((visibility("default"))) int im360_shard_pack(const void* src, void* dst, int64_t B, int64_t Fl, int64_t P, int64_t C, int64_t W,
                                 int64_t PP, int dir, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(src && dst, "shard_pack: null pointer");
@@ -337,7 +337,7 @@ extern "C" int im360_shard_pack(const void* src, void* dst, int64_t B, int64_t F
 }
 
 // y[r] = LN(x[r] + pre[r % pre_period]) * gamma + beta + post[(r / post_div) % post_mod]; pre/post optional
-extern "C" int im360_layernorm(const void* x, const void* gamma, const void* beta, const void* pre, const void* post,
+extern "C" __attribute__((visibility("default"))) int im360_layernorm(const void* x, const void* gamma, const void* beta, const void* pre, const void* post,
                                void* y, int64_t rows, int64_t C, int64_t pre_period, int64_t post_div,
                                int64_t post_mod, float eps, int dtype, void* stream) {
     using namespace im360;
@@ -357,7 +357,7 @@ extern "C" int im360_layernorm(const void* x, const void* gamma, const void* bet
 }
 
 // h [rows, 2*I] -> out [rows, I] = h[:, :I] * gelu(h[:, I:])
-extern "C" int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream) {
+extern "C" __attribute__((visibility("default"))) int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(h && out, "geglu: null pointer");
     IM360_CHECK_ARG(rows > 0 && I > 0 && (I % 8) == 0, "geglu: I=%ld must be a multiple of 8", (long)I);
@@ -380,7 +380,7 @@ extern "C" int im360_geglu(const void* h, void* out, int64_t rows, int64_t I, in
 
 // y[r, c] = softmax_c(x[r, c] * scale) over `cols` (a multiple of 8) columns of `rows` rows; row strides in elements
 // (multiples of 8); fp32 arithmetic.  x == y (in place) is allowed.
-extern "C" int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
+extern "C" __attribute__((visibility("default"))) int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t cols, int64_t x_rs, int64_t y_rs,
                                   float scale, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && y, "softmax_rows: null pointer");
@@ -405,7 +405,7 @@ extern "C" int im360_softmax_rows(const void* x, void* y, int64_t rows, int64_t 
 }
 
 // out_f16[i] = fp16(bias[i] * log2(e)), i < n: once per bias matrix (they are cached per resolution)
-extern "C" int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, void* stream) {
+extern "C" __attribute__((visibility("default"))) int im360_attn_pack_bias(const void* bias, void* out_f16, int64_t n, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(bias && out_f16 && n > 0, "attn_pack_bias: null pointer / empty");
     const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -477,7 +477,7 @@ static inline int pick_slabs(long N, long HW) {
 
 }  // namespace im360
 
-extern "C" int64_t im360_gn_num_slabs(int64_t N, int64_t H, int64_t W) { return im360::pick_slabs(N, H * W); }
+extern "C" __attribute__((visibility("default"))) int64_t im360_gn_num_slabs(int64_t N, int64_t H, int64_t W) { return im360::pick_slabs(N, H * W); }
 
 namespace im360 {
 template <typename T>
@@ -509,7 +509,7 @@ static void launch_gn_apply(const void* xa, const void* xb, int64_t C1, int64_t 
 
 // x [N,H,W,C]; partial: fp32 workspace of N * S * 2 * C floats with S = im360_gn_num_slabs(N,H,W);
 // scale, shift: fp32 [N, C] outputs.
-extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, void* partial,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_stats(const void* x, const void* gamma, const void* beta, void* partial,
                                      void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C,
                                      int64_t G, int64_t pad, float eps, int dtype, void* stream) {
     using namespace im360;
@@ -528,7 +528,7 @@ extern "C" int im360_groupnorm_stats(const void* x, const void* gamma, const voi
 }
 
 // Per-slab partial sums only (no finalize, no pad weighting): partial fp32 [N][S][2][C], S = im360_gn_num_slabs(N, H, W).
-extern "C" int im360_groupnorm_partial(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_partial(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && partial, "groupnorm_partial: null pointer");
     IM360_CHECK_ARG(N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "groupnorm_partial: bad shape");
@@ -545,7 +545,7 @@ extern "C" int im360_groupnorm_partial(const void* x, void* partial, int64_t N, 
 // scale / shift [N, C1 + C2] from partial sums: channels [0, C1) from pa ([N][Sa][2][C1]), [C1, C1 + C2) from pb ([N][Sb][2][C2];
 // pb may be null with C2 = 0).  The partial sums come from im360_groupnorm_partial or from the epilogue of the kernel that
 // produced the tensor (im360_conv_fwd / im360_linear_fwd, gn_partial).  count = H * W pixels per image.
-extern "C" int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, const void* pb, int64_t Sb, int64_t C2, const void* gamma,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, const void* pb, int64_t Sb, int64_t C2, const void* gamma,
                                         const void* beta, void* scale, void* shift, int64_t N, int64_t G, int64_t pixels, float eps,
                                         int dtype, void* stream) {
     using namespace im360;
@@ -565,7 +565,7 @@ extern "C" int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, 
 // GroupNorm statistics of the channel concatenation [xa | xb] without materialising it (xa [N,H,W,C1], xb [N,H,W,C2];
 // gamma / beta / scale / shift span C1 + C2 channels; partial: N * S * 2 * (C1 + C2) floats).  The decoder's ResnetBlocks
 // normalise torch.cat([x, skip]) (src/models/MVGenModel.py:407-437 -> animatediff/models/resnet.py:221-225).
-extern "C" int im360_groupnorm_stats_cat(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_stats_cat(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
                                          void* scale, void* shift, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2,
                                          int64_t G, int64_t pad, float eps, int dtype, void* stream) {
     using namespace im360;
@@ -584,7 +584,7 @@ extern "C" int im360_groupnorm_stats_cat(const void* xa, const void* xb, const v
 }
 
 // y [N, H, W + 2 pad, C] = act(x * scale + shift) with circular W addressing; act: 0 none, 1 SiLU
-extern "C" int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
                                      int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
                                      int dtype, void* stream) {
     using namespace im360;
@@ -603,7 +603,7 @@ extern "C" int im360_groupnorm_apply(const void* x, const void* scale, const voi
 
 // y [N, H, W + 2 pad, C1 + C2] = act([xa | xb] * scale + shift): the normalised concatenation is written directly, the
 // concatenation itself never exists (see im360_groupnorm_stats_cat)
-extern "C" int im360_groupnorm_apply_cat(const void* xa, const void* xb, const void* scale, const void* shift, void* y,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_apply_cat(const void* xa, const void* xb, const void* scale, const void* shift, void* y,
                                          int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t pad, int act,
                                          int dtype, void* stream) {
     using namespace im360;
@@ -625,7 +625,7 @@ extern "C" int im360_groupnorm_apply_cat(const void* xa, const void* xb, const v
 // S = im360_gn_num_slabs(N, H, W); counter: N int32 (zeroed here, on the stream).  xb may be null (C2 = 0).  Same bits as
 // im360_groupnorm_stats + im360_groupnorm_apply.
 // Replaces: InflatedGroupNorm / nn.GroupNorm (+ F.silu, + pad_pano) as the two functions above; one pass over HBM less.
-extern "C" int im360_groupnorm_fused(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_fused(const void* xa, const void* xb, const void* gamma, const void* beta, void* partial,
                                      void* counter, void* y, int64_t N, int64_t H, int64_t W, int64_t C1, int64_t C2,
                                      int64_t G, int64_t pad, float eps, int act, int dtype, void* stream) {
     using namespace im360;
@@ -659,7 +659,7 @@ extern "C" int im360_groupnorm_fused(const void* xa, const void* xb, const void*
 }
 
 // x [rows, W, C] -> y [rows, W + 2 pad, C], circular along W (16-bit elements, C % 8 == 0)
-extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
+extern "C" __attribute__((visibility("default"))) int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_t W, int64_t C, int64_t pad,
                                     int dtype, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && y, "circular_pad_w: null pointer");
@@ -677,7 +677,7 @@ extern "C" int im360_circular_pad_w(const void* x, void* y, int64_t rows, int64_
 
 // x [N, H, W] -> y [N, H + top + bottom, W + left + right], circular in both axes; elements of `esize` bytes (1, 2, 4, 8).
 // Each pad must not exceed the size of its axis (torch's rule for mode="circular").
-extern "C" int im360_circular_pad_hw(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t left, int64_t right,
+extern "C" __attribute__((visibility("default"))) int im360_circular_pad_hw(const void* x, void* y, int64_t N, int64_t H, int64_t W, int64_t left, int64_t right,
                                      int64_t top, int64_t bottom, int64_t esize, void* stream) {
     using namespace im360;
     IM360_CHECK_ARG(x && y, "circular_pad_hw: null pointer");
@@ -706,7 +706,7 @@ extern "C" int im360_circular_pad_hw(const void* x, void* y, int64_t N, int64_t 
 }
 
 // out = cx * x + cv * (uncond + g (cond - uncond)), n elements (n % 8 == 0), all same dtype
-extern "C" int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
+extern "C" __attribute__((visibility("default"))) int im360_cfg_ddim_update(const void* uncond, const void* cond, const void* x, void* out, int64_t n,
                                      float guidance, float cx, float cv, int dtype, void* stream, const void* coef_dev) {
     using namespace im360;
     IM360_CHECK_ARG(uncond && cond && x && out, "cfg_ddim_update: null pointer");

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void remap_cubic_wrap_u8_kernel(const uint8_t*
 
 // out[n][m] = cv2.remap(img[n], map_x[m], map_y[m], INTER_CUBIC, borderMode=BORDER_WRAP) for uint8 images [N, H, W, C]
 // (C = 1, 3 or 4), float32 maps [M, h, w] in source pixels, wtab = the 1024 x 16 int16 bicubic weight table.
-extern "C" int im360_remap_cubic_wrap_u8(const void* img, const void* map_x, const void* map_y, const void* wtab, void* out,
+extern "C" __attribute__((visibility("default"))) int im360_remap_cubic_wrap_u8(const void* img, const void* map_x, const void* map_y, const void* wtab, void* out,
                                          int64_t N, int64_t M, int64_t H, int64_t W, int64_t C, int64_t h, int64_t w,
                                          void* stream) {
     using namespace im360;
@@ -94,7 +94,7 @@ extern "C" int im360_remap_cubic_wrap_u8(const void* img, const void* map_x, con
 // order and tie-breaking of the reference's pure-Python get_maxrec_cord (src/modules/utils.py:39-73: column heights, one
 // monotone stack per row, the first strictly larger area wins).  Host code on purpose: it is a sequential O(H W) scan of a
 // mask the host already holds (the reference spends ~0.1 s per frame in Python loops on it).
-extern "C" int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect) {
+extern "C" __attribute__((visibility("default"))) int im360_max_rect(const uint8_t* mask, int64_t H, int64_t W, int64_t* rect) {
     IM360_CHECK_ARG(mask && rect && H > 0 && W > 0, "max_rect: null pointer / empty mask");
     IM360_CHECK_ARG(H * W <= (1L << 31), "max_rect: mask too large");
     int* dp = (int*)malloc(sizeof(int) * (size_t)W);

@@ -357,7 +357,7 @@ static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
 
 }  // namespace im360
 
-extern "C" int im360_temporal_attn_fwd(const void* q, const void* k, const void* v, void* out,
+extern "C" __attribute__((visibility("default"))) int im360_temporal_attn_fwd(const void* q, const void* k, const void* v, void* out,
                                        int64_t B, int64_t F, int64_t P, int64_t heads, int64_t d,
                                        int64_t qkv_fs, int64_t qkv_ps, int64_t qkv_bs,
                                        int64_t o_fs, int64_t o_ps, int64_t o_bs,

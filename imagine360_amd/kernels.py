@@ -97,15 +97,22 @@ def lib():
             raise RuntimeError(f"{_LIB_PATH} is missing: build it with `make -C imagine360_amd/csrc` "
                                "(hipcc --offload-arch=gfx950); imagine360_amd has no CPU fallback")
         L = ctypes.CDLL(_LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        have = L.im360_abi_version()
+        # the version first: a stale library that lacks a newer symbol must fail with the rebuild message, not with an
+        # AttributeError from the loop below
+        try:
+            ver = L.im360_abi_version
+        except AttributeError:
+            raise RuntimeError(f"{_LIB_PATH} exports no im360_abi_version: rebuild it with `make -C imagine360_amd/csrc`") from None
+        ver.restype, ver.argtypes = _SIGNATURES["im360_abi_version"]
+        have = ver()
         if have != ABI_VERSION:
             # (version 1 -> 2 added a trailing pointer to two entry points; a stale library would read garbage for it)
             raise RuntimeError(f"{_LIB_PATH} reports C-ABI version {have}, this binding is written for version {ABI_VERSION}: "
                                "rebuild it with `make -C imagine360_amd/csrc`")
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
         _lib = L
     return _lib
 

@@ -225,8 +225,11 @@ class MultiViewBaseModel(nn.Module):
         """The side stream is used inside a hipGraph capture (where stream dependencies become graph edges and memory comes from
         the graph's private pool) -- the default, timed path; verified bit-identical to the one-stream eager step at full size by
         bench.py's parity_check and tests/test_model_gpu.py.  Eagerly issued steps stay on one stream unless ``dual_stream_eager``
-        is set: round 4 found the eager two-stream step at cfg2 size intermittently not bit-identical (one bench run in two),
-        i.e. a lifetime hazard across the two allocator pools that capture does not have; eager issue is host-bound anyway."""
+        is set.  History: round 4 saw the eager two-stream step at cfg2 size not bit-identical in one bench run of two; round 5 could
+        NOT reproduce it (60 instrumented runs on two boxes bit-identical, profiles/r05_dual_stream_race.log) after removing two debug
+        dictionaries that pinned every down-block output -- whether that was the cause is unknown, so the hazard counts as "not
+        reproduced", not as "fixed": eager issue stays on one stream (it is host-bound anyway), GraphedDenoiseStep's warm-up sets
+        ``dual_stream_eager`` so that both allocator pools exist before the capture (its outputs are discarded)."""
         if not self.dual_stream or (self._sharded and not (self.dual_stream_shard and self._shard_two_comms)):
             return False
         return self.dual_stream_eager or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())

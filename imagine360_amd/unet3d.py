@@ -287,6 +287,10 @@ class VersatileAttention(QKVAttention):
             return None
         if f0 is None:
             f0 = self.frame_shard.f0 if self.frame_shard is not None else 0
+        # (the reference's `x + pe[:, :x.size(1)]` raises on a clip longer than the table; a short slice here would make the
+        #  kernels wrap frame positions onto wrong rows -- ADVICE r5)
+        if f0 + frames > self.pos_encoder.pe.shape[1]:
+            raise ValueError(f"frames {f0} .. {f0 + frames - 1} exceed temporal_position_encoding_max_len = {self.pos_encoder.pe.shape[1]}")
         key = (f0, frames, dtype, self.pos_encoder.pe.device)
         if getattr(self, "_pe_key", None) != key:
             self._pe_key, self._pe_val = key, self.pos_encoder.pe[0, f0:f0 + frames].to(dtype).contiguous()

@@ -27,7 +27,9 @@ def test_library_exports_nothing_the_header_does_not_declare():
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "imagine360_amd", "libim360_kernels.so")],
                          capture_output=True, text=True, check=True).stdout
-    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("im360_")})
+    # EVERY defined dynamic symbol (seven mangled C++ internals used to leak beside the C ABI; the library is
+    # now linked with csrc/exports.map)
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split()})
     assert exported == declared_symbols(), sorted(set(exported) ^ set(declared_symbols()))
 
 
@@ -52,7 +54,8 @@ def test_python_binding_covers_header():
 # reach may not (a 688-byte private array in the 256 x 64 conv tile made cfg1's convolutions 8x slower for a round, unnoticed)
 _SPILL_ALLOWED = ("temporal_attn_lds_kernel",                       # scalar fallback (knob tattn_scalar / > 64 frames)
                   "Li2ELi2ELi3ELi5E",                               # 192 x 320 four-wave tile (knob conv_big 4)
-                  "Li64ELi4ELi1ELi2ELi2ELi0E")                      # 256 x 64 tile with 64-channel K steps (knob conv_small 1)
+                  "Li64ELi4ELi1ELi2ELi2ELi0E",                      # 256 x 64 tile with 64-channel K steps (knob conv_small 1)
+                  "gemm_g4_kernelIDF16bLi2E", "gemm_g4_kernelIDF16_Li2E")      # four-wave tile with the plain epilogue (knob conv_ring 12, A/B only): hipcc moves accumulators through scratch in the epilogue
 
 
 # minimum waves per SIMD the registers of a default-path kernel must allow (gfx950: 512 registers per lane and SIMD, allocated
@@ -66,6 +69,8 @@ _MIN_WAVES = (("attn_pipe_kernel", 2),
               ("attn_fwd_kernel", 2),
               (r"conv_igemm_kernel.*Li2ELi2ELi3ELi5E", 1),        # (ablation builds only) four-wave 192 x 320 tile: the whole register file
               ("conv_igemm_kernel", 2), ("conv_ring_kernel", 2), ("conv_halo_kernel", 2),
+              ("gemm_g4b_kernel", 2),                             # round 6: 256 x 128 tile, two workgroups per CU (A/B variant)
+              ("gemm_g4_kernel", 1),                              # round 6: 256 x 256 tile on one wave per SIMD: the whole register file
               ("temporal_attn_mfma", 2))
 
 
