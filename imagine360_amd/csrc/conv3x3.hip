@@ -164,8 +164,13 @@ __device__ __forceinline__ void epi_ln_row_stats(const ConvParams& p, long m0, i
 // ZACC (the four-wave tile, conv3x3_g4.hip): the accumulators live in AGPRs (asm constraint "a") and the next tile accumulates into
 // them from its first MFMA; once a pixel block's values have left the registers its TN accumulators are cleared by one MFMA each with
 // zero operands and C = 0 (the matrix pipe is idle during the epilogue; 256 v_accvgpr_write would cost 1000 issue cycles per tile).
-template <typename T> __device__ __forceinline__ void zero_acc_mfma(f32x16& d) {
+template <typename T, bool VG = false> __device__ __forceinline__ void zero_acc_mfma(f32x16& d) {       // VG: this accumulator lives in VGPRs (the 256 x 320 tile's fifth cout block)
     const u32x4 z = {0u, 0u, 0u, 0u};
+    if constexpr (VG) {
+        if constexpr (std::is_same<T, __bf16>::value) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0\n\ts_nop 11" : "=v"(d) : "v"(z));
+        else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0\n\ts_nop 11" : "=v"(d) : "v"(z));
+        return;
+    }
     // (s_nop 11: the wait states an 8-pass MFMA result needs before anything but an accumulating MFMA may touch it -- hipcc does not know
     //  what the statement is and may copy / spill the output right behind it; s_nop 1 in front: VALU write of z -> MFMA operand)
     if constexpr (std::is_same<T, __bf16>::value) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0\n\ts_nop 11" : "=a"(d) : "v"(z));
@@ -273,7 +278,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     *(uint2*)(wlds + col * ROWB + (((i * 4 + g) ^ fr) << 4) + ((hi ^ br) << 3)) = o;
                 }
             });
-            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T>(acc[decltype(ac)::value][b]); });
+            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T, (TN == 5 && decltype(ac)::value == 4)>(acc[decltype(ac)::value][b]); });
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -435,7 +440,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T>(acc[decltype(ac)::value][b]); });
+            if constexpr (ZACC) static_for<TN>([&](auto ac) { zero_acc_mfma<T, (TN == 5 && decltype(ac)::value == 4)>(acc[decltype(ac)::value][b]); });
             load_res(NIT1, NIT);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
