@@ -24,7 +24,8 @@ extern "C" __attribute__((visibility("default"))) const char* im360_last_error(v
 
 // 2 (round 5): im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer, im360_linear_ln_fwd's table rows include c2
 // (round 4 changed both without bumping the number; callers built against version 1 must not load this library)
-extern "C" __attribute__((visibility("default"))) int im360_abi_version(void) { return 2; }
+// 3 (round 6): im360_attn_fwd takes the block maps of its packed bias matrices (three trailing arguments)
+extern "C" __attribute__((visibility("default"))) int im360_abi_version(void) { return 3; }
 
 // bit 0: built with -DIM360_ABLATE (`make ablate`): the rejected A/B variants and the ablation kernels are in the library
 extern "C" __attribute__((visibility("default"))) int im360_build_flags(void) {

@@ -118,7 +118,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
     long set_k_rs = p.k_rs, set_v_rs = p.v_rs;
     int set_nk = p.Nk;
     const T* bias = (const T*)p.bias;
-    if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) bias = (const T*)p.bias_alt;
+    const uint32_t* blk = p.bias_blocks;
+    if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) {
+        bias = (const T*)p.bias_alt;
+        blk = p.bias_blocks_alt;
+    }
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 dc + 8 hi .. +7] * scale * log2(e)
     int qrow[QB];
@@ -220,7 +224,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
     u32x4 breg[BF_LDS ? BLD : 1];
     const int brow = lane >> 2, bch = lane & 3;      // BL loader: instruction i covers mask rows 16 i + brow, 16-byte chunk bch
     uint4* const bw_lds = b_lds + (BF_LDS ? wid * BROWS * 4 : 0);
-    auto fetch_half = [&](int key_base, auto bufc) {
+    // Block map (BF_AHEAD = the WarpAttn kernel): WarpAttn's cached masks are shifted so that the ~97 % background is exactly zero
+    // (softmax is invariant under a per-row constant; mv_model.py), and one bit per (32-query block, 32-key half) says whether a
+    // block holds anything else.  A clear bit skips the block's two fragment loads (64 scattered lines per instruction) and its two
+    // bias MFMAs: 4 instead of 6 MFMAs per block.  The map row of the wave's QB blocks is read a word (32 halves = 16 tiles) at a time
+    // through the scalar cache; decisions are wave-uniform branches.
+    const bool use_blk = BF_AHEAD && blk != nullptr;
+    const int qblk = __builtin_amdgcn_readfirstlane(q0 >> 5);
+    const int nqblk = (p.Nq + 31) >> 5;
+    uint32_t blkw[QB], blkn[QB];           // the words that hold halves 2 t .. 2 t + 1 and (at a word's last tile) half 2 t + 2
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) blkw[qb] = blkn[qb] = 0xffffffffu;
+    auto blk_word = [&](int qb, int w) -> uint32_t {
+        const int r = qblk + qb < nqblk ? qblk + qb : nqblk - 1;
+        return w < p.blocks_rs ? __builtin_nontemporal_load(blk + (long)r * p.blocks_rs + w) : 0u;
+    };
+    // bit qb of the result: block qb of this wave needs the bias of 32-key half `h`
+    auto blk_need = [&](int h, int t) -> unsigned {
+        if (!use_blk) return (1u << QB) - 1u;
+        unsigned m = 0;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const uint32_t w = (h >> 5) == (t >> 4) ? blkw[qb] : blkn[qb];
+            m |= ((w >> (h & 31)) & 1u) << qb;
+        }
+        return m;
+    };
+    auto fetch_half = [&](int key_base, auto bufc, unsigned need = ~0u) {
         constexpr int buf = decltype(bufc)::value;
         if constexpr (BF_LDS) {
             // global -> registers, one 32-key half ahead of its use
@@ -233,10 +263,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         } else if constexpr (BF_AHEAD) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
+                if ((need >> qb) & 1u) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int key0 = min(key_base + 16 * c + 8 * hi, set_nk - 8);
-                    bfh[buf][qb][c] = *(const uint4*)(bias + (long)qrow[qb] * p.bias_rs + key0);
+                    for (int c = 0; c < 2; ++c) {
+                        const int key0 = min(key_base + 16 * c + 8 * hi, set_nk - 8);
+                        bfh[buf][qb][c] = *(const uint4*)(bias + (long)qrow[qb] * p.bias_rs + key0);
+                    }
                 }
         }
     };
@@ -247,6 +279,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         const T* kf = k_lds2 + (t & 1) * KT + kfrag;
         const T* vf = v_lds2 + (t & 1) * VT + vfrag;
         const int kv0 = t * KVB;
+        unsigned need_h[3] = {~0u, ~0u, ~0u};        // query blocks that need the bias of halves 2 t, 2 t + 1, 2 t + 2 (the last one is fetched ahead)
+        if constexpr (BF_AHEAD) {
+            if (use_blk) {
+                if ((t & 15) == 0) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) blkw[qb] = t == 0 ? blk_word(qb, 0) : blkn[qb];
+                }
+                if ((t & 15) == 15) {
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) blkn[qb] = blk_word(qb, (t >> 4) + 1);
+                }
+                need_h[0] = blk_need(2 * t, t);
+                need_h[1] = blk_need(2 * t + 1, t);
+                need_h[2] = blk_need(2 * t + 2, t);
+            }
+        }
 
         // bias words first (per tile at QB = 1, per half otherwise): their L2 latency hides under the QK^T MFMAs
         uint2 bw[HAS_BIAS && !BF ? QB : 1][2][4];
@@ -274,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
                 fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 0>{});
             } else if constexpr (BF_AHEAD) {
                 // this half's fragments are already in bfh[kb]; request the next half (of this tile or the next one)
-                fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 1 - kb>{});
+                fetch_half(kv0 + (kb + 1) * 32, std::integral_constant<int, 1 - kb>{}, need_h[kb + 1]);
             } else if constexpr (BF) {
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
@@ -315,9 +363,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
             if constexpr (BF) {
 #pragma unroll
                 for (int qb = all ? 0 : q1; qb < (all ? QB : q1 + 1); ++qb)
+                    if (!BF_AHEAD || ((need_h[kb] >> qb) & 1u)) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        s[qb][kb] = Elem<_Float16>::mfma32(idA[c], BF_LDS ? bfh[0][BF_LDS ? qb : 0][c] : (BF_AHEAD ? bfh[kb][BF_AHEAD ? qb : 0][c] : bfm[qb][QK_ALL ? kb : 0][c]), s[qb][kb]);
+                        for (int c = 0; c < 2; ++c)
+                            s[qb][kb] = Elem<_Float16>::mfma32(idA[c], BF_LDS ? bfh[0][BF_LDS ? qb : 0][c] : (BF_AHEAD ? bfh[kb][BF_AHEAD ? qb : 0][c] : bfm[qb][QK_ALL ? kb : 0][c]), s[qb][kb]);
+                    }
             }
         };
         // online-softmax update of block qb over the halves [K0, K1), then O^T += V^T P^T for them
@@ -1006,7 +1056,8 @@ extern "C" __attribute__((visibility("default"))) int im360_attn_fwd(const void*
                               int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                               int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
                               int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
-                              const void* bias_alt, const void* bias_sel) {
+                              const void* bias_alt, const void* bias_sel,
+                              const void* bias_blocks, const void* bias_blocks_alt, int64_t blocks_rs) {
     using namespace im360;
     IM360_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
     IM360_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attn_fwd: empty problem B=%ld H=%ld Nq=%ld Nk=%ld",
@@ -1032,6 +1083,9 @@ extern "C" __attribute__((visibility("default"))) int im360_attn_fwd(const void*
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.out = out;
     p.bias_alt = bias_alt; p.bias_sel = (const int*)bias_sel;
     IM360_CHECK_ARG(!bias_sel || (bias && bias_alt && ((uintptr_t)bias_alt % 8) == 0), "attn_fwd: bias_sel needs bias and an aligned bias_alt");
+    IM360_CHECK_ARG(!bias_blocks || (bias_packed && blocks_rs * 32 * 32 >= Nk && ((uintptr_t)bias_blocks % 4) == 0 && (!bias_alt || bias_blocks_alt)),
+                    "attn_fwd: a block map needs a packed bias, ceil(Nk / 1024) <= blocks_rs words per row and one map per bias matrix");
+    p.bias_blocks = (const uint32_t*)bias_blocks; p.bias_blocks_alt = (const uint32_t*)bias_blocks_alt; p.blocks_rs = (int)blocks_rs;
     p.B = (int)B; p.H = (int)H; p.Nq = (int)Nq; p.Nk = (int)Nk; p.kv_group = (int)kv_group;
     p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs;
     p.o_bs = o_bs; p.o_rs = o_rs; p.bias_rs = bias_rs;

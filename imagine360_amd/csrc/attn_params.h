@@ -14,6 +14,9 @@ struct AttnParams {
     float out_scale;     // multiplies the normalised result
     int accumulate;      // out += result instead of out = result
     int bias_packed;     // bias / bias_alt are fp16 matrices pre-multiplied by log2(e) (im360_attn_pack_bias)
+    // packed bias only (round 6): one bit per (32-query block, 32-key half), row stride blocks_rs words: 0 = every entry of that 32 x 32
+    // block of the packed matrix is zero, the kernel then skips its fragment loads and its two bias MFMAs.  nullptr: no map.
+    const uint32_t* bias_blocks = nullptr; const uint32_t* bias_blocks_alt = nullptr; int blocks_rs = 0;
     // optional SECOND key/value set of the same queries (DUAL kernels): out = out_scale * attn(q, k, v) + out_scale2 *
     // attn(q, k2, v2), two independent softmaxes -- the text + IP-adapter cross attention in ONE launch
     const void* k2; const void* v2;

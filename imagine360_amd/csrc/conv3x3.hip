@@ -2025,9 +2025,7 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_fwd(const voi
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "linear_fwd: null pointer");
     IM360_CHECK_ARG(M > 0 && M <= 0x7fffffffL && K > 0 && (K % 32) == 0, "linear_fwd: K=%ld must be a positive multiple of 32", (long)K);
-    // the four-wave register-staged tile (conv3x3_g4.hip; knob conv_ring 12): 256-column tiles
-    const bool g4_ok = knob(KNOB_CONV_RING) == 12 && !rowstats && !gn_partial && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (N % 256) == 0 && (M / 256) * (N / 256) >= 256;
-    IM360_CHECK_ARG(N > 0 && ((N % 320) == 0 || g4_ok), "linear_fwd: N=%ld must be a positive multiple of 320", (long)N);
+    IM360_CHECK_ARG(N > 0 && (N % 320) == 0, "linear_fwd: N=%ld must be a positive multiple of 320", (long)N);
     IM360_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
                     ((uintptr_t)res % 16) == 0 && ((uintptr_t)bias % 8) == 0 && ((uintptr_t)rowstats % 8) == 0, "linear_fwd: misaligned pointer");
     IM360_CHECK_ARG(dtype == 0 || dtype == 1, "linear_fwd: dtype %d unsupported", dtype);
@@ -2041,7 +2039,6 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_fwd(const voi
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PROF_GEMM, stream);
     const int kr = knob(KNOB_CONV_RING);
-    if (g4_ok) return dtype == 0 ? launch_g4_t<__bf16, 2>(p, s) : launch_g4_t<_Float16, 2>(p, s);
     const int v = kr == 5 ? 1 : (kr == 7 ? 6 : kr);
     if (rowstats) return dtype == 0 ? launch_ring_t<__bf16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1) : launch_ring_t<_Float16, 5, 5, true>(p, s, (v == 8 || v == 10 || v == 11) ? v : 1);
     return dtype == 0 ? launch_ring_t<__bf16, 5, 2, true>(p, s, v) : launch_ring_t<_Float16, 5, 2, true>(p, s, v);

@@ -58,7 +58,8 @@ enum { FIRST = 0, MID = 1, LAST = 2 };
 
 }  // namespace g4
 
-// EPI: 1 = GEGLU, 2 = bias (+ residual), 4 = GEGLU with the LayerNorm folded in (see tile_epilogue).  NPH_ODD: K / 64 is odd (a tile's
+// EPI: 1 = GEGLU, 4 = GEGLU with the LayerNorm folded in (see tile_epilogue; 2 = bias (+ residual) compiles, but hipcc moves the
+// accumulators through scratch in that epilogue and the launcher does not offer it).  NPH_ODD: K / 64 is odd (a tile's
 // first stage then alternates between the two buffers from tile to tile; the code is straight-line per parity).
 // ABL (ablation builds, knob conv_dbg; results are garbage): 1 no load / write stream, 2 no MFMA, 4 no fragment reads, 8 no epilogue
 template <typename T, int EPI, bool NPH_ODD, int RESM = 0, int ABL = 0>
@@ -617,26 +618,18 @@ static int launch_g4_t(ConvParams p, hipStream_t stream) {
         p.ngroups = grid >= 8u * ng ? ng : 1;
     }
     const bool odd = ((p.Cin / 64) & 1) != 0;
-    if constexpr (EPI == 2) {
-        if (odd) {
-            if (p.res) hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, true, 1>), dim3(grid), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, true, 2>), dim3(grid), dim3(256), 0, stream, p);
-        } else {
-            if (p.res) hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, false, 1>), dim3(grid), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, false, 2>), dim3(grid), dim3(256), 0, stream, p);
-        }
-    } else {
+    static_assert(EPI == 1 || EPI == 4, "built for the fused GEGLU epilogues (the plain epilogue on this tile was measured 7 - 33 % slower than the 256 x 320 loop: profiles/r06_g4_first_ab.log)");
 #ifdef IM360_G4_ABL
-        if constexpr (EPI == 1 && std::is_same<T, __bf16>::value) {
-            const int dbg = knob(KNOB_CONV_DBG);
+    if constexpr (EPI == 1 && std::is_same<T, __bf16>::value) {
+        // ablation / cycle-stamp builds (make CXXFLAGS+=-DIM360_G4_ABL; tools/g4_stamps.py, knob conv_dbg): 16 = stamps, +1 no stream, +8 no epilogue
+        const int dbg = knob(KNOB_CONV_DBG);
 #define IM360_G4_CASE(a) if (dbg == a) { if (odd) hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, true, 0, a>), dim3(grid), dim3(256), 0, stream, p); else hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, false, 0, a>), dim3(grid), dim3(256), 0, stream, p); IM360_CHECK_LAUNCH(); return IM360_OK; }
-            IM360_G4_CASE(16) IM360_G4_CASE(17) IM360_G4_CASE(25)
+        IM360_G4_CASE(16) IM360_G4_CASE(17) IM360_G4_CASE(25)
 #undef IM360_G4_CASE
-        }
-#endif
-        if (odd) hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, true, 0>), dim3(grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, false, 0>), dim3(grid), dim3(256), 0, stream, p);
     }
+#endif
+    if (odd) hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, true, 0>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_g4_kernel<T, EPI, false, 0>), dim3(grid), dim3(256), 0, stream, p);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

@@ -20,7 +20,7 @@ _SIGNATURES = {
     "im360_abi_version": (_INT, []),
     "im360_build_flags": (_INT, []),
     "im360_last_error": (ctypes.c_char_p, []),
-    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR]),
+    "im360_attn_fwd": (_INT, [_PTR] * 5 + [_I64] * 15 + [_F32, _F32, _INT, _INT, _PTR, _PTR, _PTR, _PTR, _PTR, _I64]),
     "im360_attn_fwd2": (_INT, [_PTR] * 6 + [_I64] * 19 + [_F32, _F32, _F32, _INT, _PTR]),
     "im360_temporal_attn_fwd": (_INT, [_PTR] * 4 + [_I64] * 11 + [_F32, _INT, _PTR]),
     "im360_shard_pack": (_INT, [_PTR] * 2 + [_I64] * 6 + [_INT, _PTR]),
@@ -55,7 +55,7 @@ _SIGNATURES = {
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
-ABI_VERSION = 2          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
+ABI_VERSION = 3          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
 
 PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
 
@@ -156,15 +156,33 @@ def pack_attn_bias(bias):
     return out
 
 
+def attn_bias_blocks(packed):
+    """Block map of a packed bias matrix [Nq, Nk] (fp16, ``pack_attn_bias``): int32 [ceil(Nq / 32), ceil(Nk / 1024)], bit h % 32 of
+    word h // 32 of row r is set when the 32 x 32 block (query rows 32 r .., keys 32 h ..) holds a non-zero entry.  The attention
+    kernel skips the bias of blocks whose bit is clear; WarpAttn shifts its masks so that the background is exactly zero
+    (softmax is invariant under a per-row constant)."""
+    nq, nk = packed.shape
+    rq, rk = -(-nq // 32), -(-nk // 32)
+    nz = torch.zeros((rq * 32, rk * 32), dtype=torch.bool, device=packed.device)
+    nz[:nq, :nk] = packed != 0
+    blocks = nz.view(rq, 32, rk, 32).any(dim=3).any(dim=1)                      # [rq, rk]
+    words = -(-rk // 32)
+    bits = torch.zeros((rq, words * 32), dtype=torch.int64, device=packed.device)
+    bits[:, :rk] = blocks.to(torch.int64)
+    w = (bits.view(rq, words, 32) << torch.arange(32, device=packed.device, dtype=torch.int64)).sum(dim=2)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
 def can_pack_attn_bias(d, nk):
     return d == 32 and nk % 8 == 0
 
 
 def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
-              bias_alt=None, bias_sel=None, bias_packed=False):
+              bias_alt=None, bias_sel=None, bias_packed=False, bias_blocks=None, bias_blocks_alt=None):
     """q [B, Nq, heads*d], k/v [B / kv_group, Nk, heads*d] (last dim contiguous, any row/batch stride),
     bias [Nq, Nk] shared by every (batch, head); with ``bias_sel`` (device int32 scalar) the kernel picks
-    ``bias_alt`` when it is non-zero.  ``bias_packed``: bias / bias_alt come from ``pack_attn_bias``.
+    ``bias_alt`` when it is non-zero.  ``bias_packed``: bias / bias_alt come from ``pack_attn_bias``; ``bias_blocks`` /
+    ``bias_blocks_alt``: their block maps (``attn_bias_blocks``) -- 32 x 32 blocks of zeros are skipped.
     Returns out [B, Nq, heads*d]."""
     _dev(q, k, v, bias, out)
     B, Nq, C = q.shape
@@ -186,7 +204,8 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
     rc = lib().im360_attn_fwd(_p(q), _p(k), _p(v), _p(bias), _p(out), B, heads, Nq, Nk, d,
                               q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                               out.stride(0), out.stride(1), bias.stride(0) if bias is not None else 0, kv_group,
-                              float(scale), float(out_scale), int(accumulate), _dt(q) + (256 if bias_packed else 0), _stream(), _p(bias_alt), _p(bias_sel))
+                              float(scale), float(out_scale), int(accumulate), _dt(q) + (256 if bias_packed else 0), _stream(), _p(bias_alt), _p(bias_sel),
+                              _p(bias_blocks), _p(bias_blocks_alt), bias_blocks.shape[1] if bias_blocks is not None else 0)
     _check(rc, "im360_attn_fwd")
     _count("attn", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
            + (0 if bias is None else bias.element_size() * Nq * Nk))
@@ -524,7 +543,7 @@ def linear(x, w_packed, n, bias=None, res=None, row_stats=False, gn_hw=None):
     _dev(x, w_packed, bias, res)
     k = x.shape[-1]
     m = x.numel() // k
-    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[1] == 1 and (n % 320 == 0 or n % 256 == 0)      # (256: the four-wave tile, knob conv_ring 12)
+    assert x.is_contiguous() and w_packed.shape[2] == k and w_packed.shape[1] == 1 and n % 320 == 0
     y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
     assert res is None or (res.is_contiguous() and res.numel() == y.numel() and res.dtype == x.dtype)
     st = torch.empty((m, n // ROW_SLICE, 2), dtype=torch.float32, device=x.device) if row_stats else None

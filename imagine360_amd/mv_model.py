@@ -13,6 +13,8 @@ What changed relative to the reference, deliberately:
 import random
 
 import torch
+
+LOG2E = 1.4426950408889634
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -67,6 +69,8 @@ class WarpAttn(nn.Module):
         self.pe = SphericalPE(dim // 4)
         self.dim = dim
         self._geom = {}
+        self._geom_extra = {}
+        self.mask_block_maps = True     # (A/B, tests) False: the kernel adds the shifted masks everywhere, no block skipping
 
     def geometry(self, ph, pw, eh, ew, cameras, opposite, device, dtype):
         fov, theta, phi = G.camera_lists(cameras)
@@ -78,13 +82,30 @@ class WarpAttn(nn.Module):
                 pers_pe = self.pe(pc.to(device)).reshape(-1, self.dim)          # (m h w) c
                 equi_pe = self.pe(ec.to(device)).reshape(-1, self.dim)          # (h w) c
                 b_e2p, b_p2e = b_e2p.to(dtype), b_p2e.to(dtype)
-                # head dim 32: the masks go to the kernel as fp16 * log2(e) and are added by the matrix pipe
+                # head dim 32: the masks go to the kernel as fp16 * log2(e) and are added by the matrix pipe.  Round 6: SHIFTED by minus
+                # their minimum -- softmax is invariant under a per-row constant, and the ~97 % of a mask that is background (-1) becomes
+                # exactly zero -- with a block map that lets the kernel skip the all-zero 32 x 32 blocks (2 of its 6 MFMAs per block and
+                # the scattered fragment loads); ``geometry_extra`` returns the maps and the shifts
                 packed = all(kernels.can_pack_attn_bias(32, b.shape[1]) for b in (b_e2p, b_p2e))
+                extra = {}
                 if packed:
-                    b_e2p, b_p2e = kernels.pack_attn_bias(b_e2p), kernels.pack_attn_bias(b_p2e)
+                    def pack(b):
+                        shift = -float(b.float().min())
+                        pm = ((b.float() + shift) * LOG2E).clamp(-60000.0, 60000.0).to(torch.float16).contiguous()
+                        return pm, kernels.attn_bias_blocks(pm), shift
+                    b_e2p, extra["blocks_e2p"], extra["shift_e2p"] = pack(b_e2p)
+                    b_p2e, extra["blocks_p2e"], extra["shift_p2e"] = pack(b_p2e)
                 self._geom[key] = (b_e2p, b_p2e, pers_pe.to(dtype), equi_pe.to(dtype), packed)
-                publish_to_all_streams(self._geom[key][:4])
+                self._geom_extra[key] = extra
+                publish_to_all_streams(self._geom[key][:4] + tuple(v for v in extra.values() if torch.is_tensor(v)))
         return self._geom[key]
+
+    def geometry_extra(self, ph, pw, eh, ew, cameras, opposite, device, dtype):
+        """Block maps (``kernels.attn_bias_blocks``) and shifts of the packed masks ``geometry`` returns for the same arguments
+        ({} when the masks are not packed): packed = fp16((mask + shift) * log2 e)."""
+        self.geometry(ph, pw, eh, ew, cameras, opposite, device, dtype)
+        fov, theta, phi = G.camera_lists(cameras)
+        return self._geom_extra[(ph, pw, eh, ew, bool(opposite), str(device), dtype, tuple(fov), tuple(theta), tuple(phi))]
 
     def forward_cl(self, pers, equi, cameras, frames, opposite=None, sel=None, side=None, diag=(False, False)):
         """pers [(b m) f, ph, pw, C], equi [b f, eh, ew, C] channels-last -> same shapes.  ``sel``: device int32
@@ -96,13 +117,19 @@ class WarpAttn(nn.Module):
         b = ne_img // frames
         m = nf // ne_img
         alt_e2p = alt_p2e = None
+        xa = {}
         if sel is not None:
             b_e2p, b_p2e, pers_pe, equi_pe, packed = self.geometry(ph, pw, eh, ew, cameras, False, pers.device, pers.dtype)
             alt_e2p, alt_p2e, _, _, _ = self.geometry(ph, pw, eh, ew, cameras, True, pers.device, pers.dtype)
+            xg = self.geometry_extra(ph, pw, eh, ew, cameras, False, pers.device, pers.dtype)
+            xa = self.geometry_extra(ph, pw, eh, ew, cameras, True, pers.device, pers.dtype)
         else:
             if opposite is None:
                 opposite = random.random() < 0.4                 # the reference's coin, one draw per call
             b_e2p, b_p2e, pers_pe, equi_pe, packed = self.geometry(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
+            xg = self.geometry_extra(ph, pw, eh, ew, cameras, opposite, pers.device, pers.dtype)
+        if not self.mask_block_maps:
+            xg, xa = {}, {}
         eq = equi.reshape(b * frames, eh * ew, c)
         # (b m) f (h w) c -> (b f) (m h w) c
         pr = pers.reshape(b, m, frames, ph * pw, c).permute(0, 2, 1, 3, 4).reshape(b * frames, m * ph * pw, c)
@@ -113,12 +140,14 @@ class WarpAttn(nn.Module):
         # residual adds ride in the GEMM epilogues where the token count takes the MFMA kernel (same rounding sequence as
         # Linear -> + residual; hipBLASLt + add otherwise)
         def equi_chain(eq):
-            a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel, bias_packed=packed)
+            a_e = kernels.attention(qkv_e[..., :c], qkv_p[..., c:2 * c], qkv_p[..., 2 * c:], h, bias=b_e2p, bias_alt=alt_e2p, bias_sel=sel, bias_packed=packed,
+                                    bias_blocks=xg.get("blocks_e2p"), bias_blocks_alt=xa.get("blocks_e2p"))
             eq, st = t.attn1.out_proj(a_e, residual=eq, row_stats=True)
             return t.ff(eq, residual=eq, ln=t.norm2, stats=st)          # LayerNorm folded into the GEGLU GEMM where both take the MFMA kernel
 
         def pers_chain(pr):
-            a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed)
+            a_p = kernels.attention(qkv_p[..., :c], qkv_e[..., c:2 * c], qkv_e[..., 2 * c:], h, bias=b_p2e, bias_alt=alt_p2e, bias_sel=sel, bias_packed=packed,
+                                    bias_blocks=xg.get("blocks_p2e"), bias_blocks_alt=xa.get("blocks_p2e"))
             pr, st = t.attn1.out_proj(a_p, residual=pr, row_stats=True)
             return t.ff(pr, residual=pr, ln=t.norm2, stats=st)
 

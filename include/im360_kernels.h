@@ -31,6 +31,11 @@ const char* im360_last_error(void);
  * kv_group: K/V batch index = query batch index / kv_group (one context per video, F frames of queries).
  * dtype: 0 bf16, 1 fp16; + 256 (D = 32 only, Nk % 8 == 0): bias and bias_alt are fp16 matrices already multiplied by
  *   log2(e) (im360_attn_pack_bias) and are added to the scores by the matrix pipe instead of the vector ALU.
+ * bias_blocks / bias_blocks_alt (optional, packed bias only; ABI version 3): block maps of bias / bias_alt -- uint32 words
+ *   [ceil(Nq / 32)][blocks_rs], bit (h % 32) of word (h / 32) of row r clear = every entry of the 32 x 32 block (queries 32 r ..,
+ *   keys 32 h ..) of the packed matrix is ZERO; the kernel skips such a block's mask loads and mask MFMAs (identical results: they
+ *   would add zeros).  The caller makes the common value of a mask zero by subtracting it from the whole matrix -- softmax is
+ *   invariant under a per-row constant (WarpAttn: ~ 80 - 90 % of the blocks are background).
  * Replaces: xformers.ops.memory_efficient_attention / F.scaled_dot_product_attention at
  *   diffusers/models/attention_processor.py:1264, 1351, 641 (spatial self / cross attention),
  *   animatediff/models/attention.py:113-148 (text + IP cross attention),
@@ -40,7 +45,8 @@ int im360_attn_fwd(const void* q, const void* k, const void* v, const void* bias
                    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs,
                    int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs, int64_t bias_rs,
                    int64_t kv_group, float scale, float out_scale, int accumulate, int dtype, void* stream,
-                   const void* bias_alt, const void* bias_sel);
+                   const void* bias_alt, const void* bias_sel,
+                   const void* bias_blocks, const void* bias_blocks_alt, int64_t blocks_rs);
 
 /* out_f16[i] = fp16(clamp(bias[i] * log2(e), -60000, 60000)) for the n elements of a bias matrix of dtype 0 / 1: the packed
  * form accepted by im360_attn_fwd with dtype + 256.  The packed entries must be FINITE (the kernel adds them with an

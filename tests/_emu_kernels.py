@@ -16,8 +16,12 @@ def pack_attn_bias(bias):
     return (bias.float() * 1.4426950408889634).half()
 
 
+def attn_bias_blocks(packed):
+    return torch.ones((-(-packed.shape[0] // 32), -(-packed.shape[1] // 1024)), dtype=torch.int32)
+
+
 def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False, out_scale=1.0, kv_group=1,
-              bias_alt=None, bias_sel=None, bias_packed=False):
+              bias_alt=None, bias_sel=None, bias_packed=False, bias_blocks=None, bias_blocks_alt=None):
     if bias_sel is not None and int(bias_sel) != 0:
         bias = bias_alt
     if bias is not None and bias_packed:

@@ -42,7 +42,7 @@ def q16(t, dt):
 
 
 def test_library_loads():
-    assert K.lib().im360_abi_version() == K.ABI_VERSION == 2
+    assert K.lib().im360_abi_version() == K.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -201,6 +201,61 @@ def test_attention_packed_bias_through_the_matrix_pipe(dt, B, H, Nq, Nk):
     with pytest.raises(RuntimeError, match="head dim 32"):
         x = torch.zeros(1, 64, 128, dtype=dt, device="cuda")
         K.attention(x, x, x, 2, bias=torch.zeros(64, 64, dtype=torch.float16, device="cuda"), bias_packed=True)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 2048, 5120), (3, 2, 576, 1288), (1, 3, 64, 2112), (2, 2, 4096, 1024)])
+def test_attention_block_map_skips_background_blocks(dt, B, H, Nq, Nk):
+    """Round 6: WarpAttn's masks shifted so that the background is exactly zero (softmax is invariant under a per-row constant) +
+    one bit per (32-query block, 32-key half) of the packed matrix (kernels.attn_bias_blocks): blocks with a clear bit skip their
+    fragment loads and their two bias MFMAs.  A skipped MFMA would have added exact zeros, so the result with the map is BIT-identical
+    to the result without it; both match the fp32 oracle on the UNSHIFTED mask.  Sizes: WarpAttn level 1, ragged query / key counts
+    (map rows and words past the end), more than 1024 keys (a second map word; the look-ahead across the word boundary), the
+    device-side switch between two matrices with different maps."""
+    g = torch.Generator().manual_seed(91)
+    D = 32
+    q, k, v = (q16(torch.randn(B, n, H * D, generator=g), dt) for n in (Nq, Nk, Nk))
+
+    def sparse_mask(seed):
+        gg = torch.Generator().manual_seed(seed)
+        m = torch.full((Nq, Nk), -1.0)
+        for _ in range(max(3, Nq * Nk // 200000)):                      # a few soft foreground patches on a -1 background
+            r0, c0 = int(torch.randint(0, Nq, (1,), generator=gg)), int(torch.randint(0, Nk, (1,), generator=gg))
+            h, w = int(torch.randint(8, 80, (1,), generator=gg)), int(torch.randint(8, 200, (1,), generator=gg))
+            m[r0:r0 + h, c0:c0 + w] = torch.rand(min(h, Nq - r0), min(w, Nk - c0), generator=gg) * 2 - 1
+        return q16(m, dt)
+
+    bias, alt = sparse_mask(1), sparse_mask(2)
+    ref, ref_alt = OU.sdpa(q, k, v, H, bias=bias), OU.sdpa(q, k, v, H, bias=alt)
+    dq, dk, dv = (t.to(dt).cuda() for t in (q, k, v))
+
+    def pack(b):
+        pm = ((b.float().cuda() + 1.0) * 1.4426950408889634).to(torch.float16).contiguous()
+        return pm, K.attn_bias_blocks(pm)
+
+    (pb, mb), (pa, ma) = pack(bias), pack(alt)
+    want_bits = torch.zeros((-(-Nq // 32) * 32, -(-Nk // 32) * 32), dtype=torch.bool, device="cuda")
+    want_bits[:Nq, :Nk] = pb != 0
+    want_bits = want_bits.view(-1, 32, want_bits.shape[1] // 32, 32).any(3).any(1)
+    words = mb.to(torch.int64) & 0xffffffff
+    got_bits = ((words[:, :, None] >> torch.arange(32, device="cuda")) & 1).reshape(words.shape[0], -1)[:, :want_bits.shape[1]].bool()
+    assert torch.equal(got_bits, want_bits) and 0.0 < float(want_bits.float().mean()) < 0.5
+    try:
+        for qb in (1, 2):                # (the map is used by the two-query-block kernel -- WarpAttn's; with one block per wave it is ignored)
+            K.tuning_set("attn_qb", qb)
+            plain = K.attention(dq, dk, dv, H, bias=pb, bias_packed=True)
+            mapped = K.attention(dq, dk, dv, H, bias=pb, bias_packed=True, bias_blocks=mb)
+            assert torch.equal(plain, mapped), qb
+            assert rel(mapped, ref) < TOL[dt] and blockrel(mapped, ref, 32) < 2 * TOL[dt], qb
+            for flag, want in ((0, ref), (1, ref_alt)):
+                sel = torch.tensor([flag], dtype=torch.int32, device="cuda")
+                out = K.attention(dq, dk, dv, H, bias=pb, bias_alt=pa, bias_sel=sel, bias_packed=True, bias_blocks=mb, bias_blocks_alt=ma)
+                assert rel(out, want) < TOL[dt] and blockrel(out, want, 32) < 2 * TOL[dt], (qb, flag)
+                assert torch.equal(out, K.attention(dq, dk, dv, H, bias=pb, bias_alt=pa, bias_sel=sel, bias_packed=True)), (qb, flag)
+    finally:
+        K.tuning_set("attn_qb", 0)
+    with pytest.raises(RuntimeError, match="block map"):
+        K.attention(dq, dk, dv, H, bias=bias.to(dt).cuda(), bias_blocks=mb)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -758,9 +758,20 @@ def test_cross_view_masks_and_tables_on_the_device_match_the_reference_fixture()
         ref_e2p = g[f"pers_{tag}_{ph}"].reshape(m, ne, npx).permute(1, 0, 2).reshape(ne, m * npx)
         ref_p2e = g[f"equi_{tag}_{ph}"].reshape(m * npx, ne)
         assert packed and b_e2p.dtype == torch.float16 and b_e2p.is_cuda and b_e2p.shape == (ne, m * npx)
-        # packed form = fp16(bf16(mask) * log2 e): undo the scale, allow the two roundings
-        assert (b_e2p.float().cpu() / 1.4426950408889634 - ref_e2p).abs().max() < 6e-3
-        assert (b_p2e.float().cpu() / 1.4426950408889634 - ref_p2e).abs().max() < 6e-3
+        # packed form = fp16((bf16(mask) + shift) * log2 e) (round 6: shifted so that the background is zero): undo both, allow the two roundings
+        xt = blk.geometry_extra(ph, ph, eh, 2 * eh, cams, tag == "oppo", dev, torch.bfloat16)
+        assert (b_e2p.float().cpu() / 1.4426950408889634 - xt["shift_e2p"] - ref_e2p).abs().max() < 6e-3
+        assert (b_p2e.float().cpu() / 1.4426950408889634 - xt["shift_p2e"] - ref_p2e).abs().max() < 6e-3
+        # the block maps: a clear bit <=> the 32 x 32 block of the packed matrix is all zero
+        for mat, bm in ((b_e2p, xt["blocks_e2p"]), (b_p2e, xt["blocks_p2e"])):
+            nq, nk = mat.shape
+            nz = torch.zeros((-(-nq // 32) * 32, -(-nk // 32) * 32), dtype=torch.bool, device=dev)
+            nz[:nq, :nk] = mat != 0
+            want = nz.view(-1, 32, nz.shape[1] // 32, 32).any(3).any(1).cpu()
+            words = bm.cpu().to(torch.int64) & 0xffffffff
+            got = ((words[:, :, None] >> torch.arange(32)) & 1).reshape(words.shape[0], -1)[:, :want.shape[1]].bool()
+            assert torch.equal(got, want)
+            assert float(want.float().mean()) < 0.6          # most blocks are background
         pc, ec = G.spherical_coords(ph, ph, eh, 2 * eh, cams)
         assert torch.equal(pc, g[f"pers_coords_{ph}"]) and torch.equal(ec, g[f"equi_coords_{ph}"])
         from im360_oracle import geometry as OG
@@ -793,8 +804,9 @@ def test_cross_view_masks_at_the_cfg5_level_1_size_on_the_device():
         k_e2p, k_p2e, pers_pe, equi_pe, packed = blk.geometry(32, 32, 64, 128, cams, tag == "oppo", dev, torch.float16)
         assert packed and k_e2p.dtype == torch.float16 and k_e2p.shape == (8192, 20480) and k_p2e.shape == (20480, 8192)
         for name, mat, rows in (("e2p", k_e2p, g["rows_e2p"]), ("p2e", k_p2e, g["rows_p2e"])):
-            # packed form = fp16(fp16(mask) * log2 e): undo the scale, allow the two fp16 roundings
-            err = float((mat[rows.to(dev)].float().cpu() / 1.4426950408889634 - g[f"{name}_{tag}_rows"].float()).abs().max())
+            # packed form = fp16((fp16(mask) + shift) * log2 e): undo scale and shift, allow the two fp16 roundings
+            shift = blk.geometry_extra(32, 32, 64, 128, cams, tag == "oppo", dev, torch.float16)[f"shift_{name}"]
+            err = float((mat[rows.to(dev)].float().cpu() / 1.4426950408889634 - shift - g[f"{name}_{tag}_rows"].float()).abs().max())
             obs[f"{tag}_{name}_packed_rows_max_abs"] = err
             assert err < 2e-3, (tag, name, err)
     pc, ec = G.spherical_coords(32, 32, 64, 128, cams)
