@@ -816,6 +816,52 @@ def test_cross_view_masks_at_the_cfg5_level_1_size_on_the_device():
     assert obs["pers_pe_max_abs"] < 1e-3 and obs["equi_pe_max_abs"] < 1e-3, obs          # fp16 table of values in [-1, 1]
 
 
+def test_warp_attn_block_at_cfg5_level_1_size_vs_oracle():
+    """ONE WarpAttn block at BASELINE cfg5's level-1 size -- equirect 64 x 128, 20 views of 32 x 32, 640
+    channels (20 heads of 32), one frame, both mask variants -- through the product (positional tables, LayerNorm + PE, fused QKV,
+    the 8192 x 20 480 and 20 480 x 8192 attentions with the shifted masks and their block maps, output projection, LayerNorm-folded
+    GEGLU feed-forward) against the fp32 oracle (im360_oracle.mv.warp_attn, attn_perspano.py:22-99) on the same weights and inputs.
+    The oracle gets the masks the product built on the device; the test above pins exactly those on the REAL get_merged_masks."""
+    from im360_oracle import mv as OMV
+    from imagine360_amd import pano_geometry as G
+    from imagine360_amd.mv_model import WarpAttn
+    dt, dev = torch.float16, torch.device("cuda", 0)
+    ph, eh, m, c = 32, 64, 20, 640
+    cams = {k: v[0] for k, v in S.icosahedron_cameras(90, 512).items()}
+    g = torch.Generator().manual_seed(17)
+    blk = WarpAttn(c)
+    with torch.no_grad():
+        for name, prm in blk.named_parameters():             # (the reference zero-initialises the output projections: fill everything)
+            if prm.dim() >= 2:
+                prm.copy_(torch.randn(prm.shape, generator=g) * prm.shape[-1] ** -0.5)
+            elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("norm3.weight"):
+                prm.copy_(1.0 + 0.1 * torch.randn(prm.shape, generator=g))
+            else:
+                prm.copy_(0.05 * torch.randn(prm.shape, generator=g))
+        blk = blk.to(dt)                                     # the weights both sides use are the fp16-rounded ones
+    sd = {"w." + k: v.float() for k, v in blk.state_dict().items()}
+    pers = _q(torch.randn(m, ph, ph, c, generator=g), dt)    # (b m) f = 20 images of one frame, channels-last
+    equi = _q(torch.randn(1, eh, 2 * eh, c, generator=g), dt)
+    gblk = blk.to(dev)
+    obs = {}
+    for tag, opp in (("normal", False), ("oppo", True)):
+        gp, ge = gblk.forward_cl(pers.to(dev, dt), equi.to(dev, dt), cams, 1, opposite=opp)
+        x = gblk.geometry_extra(ph, ph, eh, 2 * eh, cams, opp, dev, dt)
+        assert x["blocks_e2p"].shape == (eh * 2 * eh // 32, m * ph * ph // 1024) and x["blocks_p2e"].shape == (m * ph * ph // 32, eh * 2 * eh // 1024)
+        b_e2p, b_p2e = G.cross_view_bias(ph, ph, eh, 2 * eh, cams, opp, dev)
+        masks = (b_e2p.float().cpu().reshape(eh, 2 * eh, m, ph, ph).permute(2, 0, 1, 3, 4), b_p2e.float().cpu().reshape(m, ph, ph, eh, 2 * eh))
+        del b_e2p, b_p2e
+        op, oe = OMV.warp_attn(sd, "w.", pers.float().permute(0, 3, 1, 2).unsqueeze(2), equi.float().permute(0, 3, 1, 2).unsqueeze(2), cams, opposite=opp, masks=masks)
+        obs[f"{tag}_pers"] = rel(gp, op[:, :, 0].permute(0, 2, 3, 1))
+        obs[f"{tag}_equi"] = rel(ge, oe[:, :, 0].permute(0, 2, 3, 1))
+        # no 32-row block of tokens off by more than a few times the tensor's error (a wrong mask block / skipped foreground block is O(1))
+        obs[f"{tag}_equi_worst_block"] = float(((ge.float().cpu() - oe[:, :, 0].permute(0, 2, 3, 1)).reshape(-1, 32, c).norm(dim=(1, 2))
+                                                / oe[:, :, 0].permute(0, 2, 3, 1).reshape(-1, 32, c).norm(dim=(1, 2))).max())
+    _record("warp_attn_block_64x128x32", **obs)
+    assert max(v for k, v in obs.items() if not k.endswith("worst_block")) < 4e-3, obs
+    assert max(v for k, v in obs.items() if k.endswith("worst_block")) < 1.6e-2, obs
+
+
 def test_preprocessing_warps_vs_oracle():
     """SURVEY row N3 on the GPU: im360_remap_cubic_wrap_u8 == the oracle's restatement of cv2.remap(INTER_CUBIC, BORDER_WRAP)
     bit for bit -- random maps incl. coordinates outside the image, exact .5 / integer positions and 1 / 3 / 4 channels --
