@@ -57,6 +57,9 @@ struct ConvParams {
     // when an image is a whole number of tiles (H W % 256 == 0: slab s of image n = tile n * (H W / 256) + s), so the consumer's
     // GroupNorm skips its own statistics pass over the tensor (animatediff/models/resnet.py:221-243: norm -> act -> conv, twice)
     float* gn_out;
+    // knob nt bit 0 (A/B): the epilogue's output rows leave with non-temporal stores (the tensors are hundreds of MB that the next
+    // kernel streams once)
+    int nt_store;
 };
 
 // ConvParams with the optional members cleared
@@ -64,6 +67,7 @@ static inline ConvParams conv_params_zero() {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.ngroups = 1;
+    p.nt_store = knob(KNOB_NT) & 1;
     return p;
 }
 
@@ -290,7 +294,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                 if (row < 32 && mr < p.M && co < I) {
                     uint4 o = *(const uint4*)(wlds + row * ROWB + ((pc ^ piece_xor(row, ROWB)) << 4));
                     if ((row >> 3) & 1) { const uint32_t t0 = o.x, t1 = o.y; o.x = o.z; o.y = o.w; o.z = t0; o.w = t1; }
-                    *(uint4*)(yg + mr * I + co) = o;
+                    if (p.nt_store) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)(yg + mr * I + co));
+                    else *(uint4*)(yg + mr * I + co) = o;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -491,7 +496,10 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, f32x16 (&acc)
                     const int yy = rem / p.Wout, xx = rem - yy * p.Wout;
                     const long orow = (nimg * (2L * p.Hout) + 2 * yy + p.up2_py) * (2L * p.Wout) + 2 * xx + p.up2_px;
                     if (ok) *(uint4*)((char*)yg + (orow * p.Cout + (co < cmax8 ? co : cmax8)) * 2) = o;
-                } else if (ok) *(uint4*)(ybase + off * 2u) = o;
+                } else if (ok) {
+                    if (p.nt_store) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)(ybase + off * 2u));
+                    else *(uint4*)(ybase + off * 2u) = o;
+                }
             }
             if constexpr (EPI == 5) {
                 // two lanes per row add up the row's pieces in a fixed order (deterministic, unlike atomics) and write the
@@ -1976,7 +1984,8 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_geglu(const v
         if (dtype == 1) return launch_conv_t<_Float16, 2, 2, 2, 4, 1>(p, s);
     }
 #endif
-    if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)       // the four-wave register-staged tile
+    // the four-wave register-staged tile: knob g4 bit 0 (or, A/B tools, conv_ring 12)
+    if (((knob(KNOB_G4) & 1) || knob(KNOB_CONV_RING) == 12) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)
         return dtype == 0 ? launch_g4_t<__bf16, 1>(p, s) : launch_g4_t<_Float16, 1>(p, s);
     if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)       // the same loop, two workgroups per CU (256 x 128 tiles)
         return dtype == 0 ? launch_g4b_t<__bf16, 1>(p, s) : launch_g4b_t<_Float16, 1>(p, s);
@@ -2096,7 +2105,7 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_geglu_ln(cons
     p.stride = 1; p.imgs_per_temb = 1;
     p.M = M;
     ProfScope prof(PROF_GEMM, stream);
-    if (knob(KNOB_CONV_RING) == 12 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)
+    if (((knob(KNOB_G4) & 2) || knob(KNOB_CONV_RING) == 12) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)       // knob g4 bit 1
         return dtype == 0 ? launch_g4_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4_t<_Float16, 4>(p, (hipStream_t)stream);
     if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)
         return dtype == 0 ? launch_g4b_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4b_t<_Float16, 4>(p, (hipStream_t)stream);

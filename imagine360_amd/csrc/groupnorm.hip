@@ -124,44 +124,90 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // The same from partial sums that need not come from gn_partial_kernel: the channels [0, C1) from `pa` (Sa slabs per image,
 // [n][s][2][C1]) and [C1, C1 + C2) from `pb` (Sb slabs, [n][s][2][C2]) -- either buffer may have been written by the epilogue
 // of the convolution / linear that produced that tensor (ConvParams::gn_out: one slab per 256-pixel tile).
-template <typename T>
-__global__ __launch_bounds__(64) void gn_finalize2_kernel(const float* __restrict__ pa, int Sa, int C1, const float* __restrict__ pb, int Sb, int C2,
-                                                          const T* __restrict__ gamma, const T* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift, int G, double count, float eps) {
-    const int C = C1 + C2;
-    const int n = blockIdx.x / G, g = blockIdx.x % G, lane = threadIdx.x;
-    const int cpg = C / G;
-    double sum = 0.0, sq = 0.0;
-    // channels of this group in the first / second source
-    const int c0 = g * cpg, c1 = c0 + cpg;
-    const int a0 = c0 < C1 ? c0 : C1, a1 = c1 < C1 ? c1 : C1;          // [a0, a1) in source a
-    const int b0 = (c0 > C1 ? c0 : C1) - C1, b1 = (c1 > C1 ? c1 : C1) - C1;      // [b0, b1) in source b
-    const int na = a1 - a0, nb = b1 - b0;
-    for (int i = lane; i < Sa * na; i += 64) {
-        const float* src = pa + ((long)n * Sa + i / na) * 2 * C1 + a0 + i % na;
-        sum += (double)src[0];
-        sq += (double)src[C1];
-    }
-    for (int i = lane; i < Sb * nb; i += 64) {
-        const float* src = pb + ((long)n * Sb + i / nb) * 2 * C2 + b0 + i % nb;
-        sum += (double)src[0];
-        sq += (double)src[C2];
-    }
+// scale / shift of every channel of image n from partial sums in two buffers, by one 256-thread workgroup -- the ONE reduction
+// order of this file's two-source paths (gn_finalize2_kernel, gn_apply_p_kernel), all in fp64:
+//   (A) thread per channel: the channel's sums over the slabs in ascending slab order (coalesced across the threads, four
+//       independent loads in flight) -> LDS;
+//   (B) eight threads per group: thread k adds the channels k, k + 8, ... of the group in ascending order, then a butterfly over the
+//       eight; mean / rstd of the group -> LDS;
+//   (C) thread per channel: put(c, rstd * gamma, beta - mean * rstd * gamma).
+// `wk`: (2 C + 2 G) doubles of LDS.  Ends with the LDS free again only after the caller's next barrier (put may write LDS that
+// overlays `wk`'s channel sums: they are dead after (B)'s barrier).
+template <typename T, typename Put>
+__device__ __forceinline__ void gn_image_scale_shift(const float* __restrict__ pa, int Sa, int C1, const float* __restrict__ pb, int Sb, int C2,
+                                                     const T* __restrict__ gamma, const T* __restrict__ beta, int n, int G, double count, float eps,
+                                                     double* wk, Put put) {
+    const int tid = threadIdx.x;
+    const int C = C1 + C2, cpg = C / G;
+    double* const gst = wk + 2 * C;
+    for (int c = tid; c < C; c += 256) {
+        const bool second = c >= C1;
+        const int S = second ? Sb : Sa, Cx = second ? C2 : C1;
+        const float* src = (second ? pb + (long)n * Sb * 2 * C2 + (c - C1) : pa + (long)n * Sa * 2 * C1 + c);
+        double sum = 0.0, sq = 0.0;
+        int sl = 0;
+        for (; sl + 4 <= S; sl += 4) {
+            float u[4], v[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sum += __shfl_xor(sum, o);
-        sq += __shfl_xor(sq, o);
+            for (int i = 0; i < 4; ++i) {
+                u[i] = src[(long)(sl + i) * 2 * Cx];
+                v[i] = src[(long)(sl + i) * 2 * Cx + Cx];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sum += (double)u[i];
+                sq += (double)v[i];
+            }
+        }
+        for (; sl < S; ++sl) {
+            sum += (double)src[(long)sl * 2 * Cx];
+            sq += (double)src[(long)sl * 2 * Cx + Cx];
+        }
+        wk[c] = sum;
+        wk[C + c] = sq;
     }
-    const double mean = sum / count;
-    double var = sq / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    for (int j = lane; j < cpg; j += 64) {
-        const int c = c0 + j;
+    __syncthreads();
+    for (int g = tid >> 3; g < ((G + 31) & ~31); g += 32) {          // (whole waves run the butterfly)
+        double sum = 0.0, sq = 0.0;
+        if (g < G)
+            for (int j = tid & 7; j < cpg; j += 8) {
+                sum += wk[g * cpg + j];
+                sq += wk[C + g * cpg + j];
+            }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sum += __shfl_xor(sum, o);
+            sq += __shfl_xor(sq, o);
+        }
+        if (g < G && (tid & 7) == 0) {
+            const double mean = sum / count;
+            double var = sq / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gst[2 * g] = mean;
+            gst[2 * g + 1] = 1.0 / sqrt(var + (double)eps);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const double mean = gst[2 * g], rstd = gst[2 * g + 1];
         const double ga = (double)to_f32(gamma[c]), be = (double)to_f32(beta[c]);
-        scale[(long)n * C + c] = (float)(rstd * ga);
-        shift[(long)n * C + c] = (float)(be - mean * rstd * ga);
+        put(c, (float)(rstd * ga), (float)(be - mean * rstd * ga));
     }
+}
+
+// grid N, 256 threads, (2 C + 2 G) doubles of dynamic LDS
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restrict__ pa, int Sa, int C1, const float* __restrict__ pb, int Sb, int C2,
+                                                           const T* __restrict__ gamma, const T* __restrict__ beta, float* __restrict__ scale,
+                                                           float* __restrict__ shift, int G, double count, float eps) {
+    extern __shared__ double gn_wk[];
+    const int C = C1 + C2;
+    const int n = blockIdx.x;
+    gn_image_scale_shift<T>(pa, Sa, C1, pb, Sb, C2, gamma, beta, n, G, count, eps, gn_wk, [&](int c, float sc, float sh) {
+        scale[(long)n * C + c] = sc;
+        shift[(long)n * C + c] = sh;
+    });
 }
 
 // ---- pass 3 -----------------------------------------------------------------------------------
@@ -220,6 +266,86 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             emit(r3, pix + 3 * lanes);
         }
         for (; pix < pix1; pix += lanes) emit(src(pix), pix);
+    }
+}
+
+// ---- passes 2 + 3 in ONE launch (the default since round 6) ---------------------------------------------------------------------
+// grid (S, N).  Every workgroup first rebuilds scale / shift of ITS image from the partial sums (a few KB per image out of the L2;
+// gn_image_scale_shift: the bits of gn_finalize2_kernel) into LDS, then normalises its slab of the
+// output -- of x, or of the never-materialised concatenation [xa | xb] -- as gn_apply_kernel does.  The finalize launch (157 per
+// denoising step, each a ~10 us chain of fp64 latencies on N x G single-wave workgroups) and the [N, C] scale / shift round trip
+// are gone; the concatenation takes one launch instead of two.  NLD: 16-byte loads in flight per thread.
+template <typename T, int NLD, bool NTS, bool NTL = false>
+__global__ __launch_bounds__(256) void gn_apply_p_kernel(const T* __restrict__ xa, const T* __restrict__ xb, int C1, int C2,
+                                                          const float* __restrict__ pa, int Sa, const float* __restrict__ pb, int Sb,
+                                                          const T* __restrict__ gamma, const T* __restrict__ beta, T* __restrict__ y,
+                                                          int H, int W, int G, int pad, int act, int S, float eps) {
+    extern __shared__ double gn_wk[];                // (2 C + 2 G) doubles; then, over the dead channel sums, [2][C] floats: scale | shift of image n
+    float* const sc_sh = (float*)gn_wk;
+    const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int C = C1 + C2;
+    gn_image_scale_shift<T>(pa, Sa, C1, pb, Sb, C2, gamma, beta, n, G, (double)H * (double)(W + 2 * pad) * (double)(C / G), eps, gn_wk,
+                            [&](int c, float sc, float sh) {
+                                sc_sh[c] = sc;
+                                sc_sh[C + c] = sh;
+                            });
+    __syncthreads();
+    const int Wo = W + 2 * pad, HWo = H * Wo;
+    const int pps = (HWo + S - 1) / S;
+    const int pix0 = s * pps, pix1 = min(HWo, pix0 + pps);
+    T* yb = y + (long)n * HWo * C;
+    for (int src = 0; src < (xb ? 2 : 1); ++src) {
+        const T* x = src ? xb : xa;
+        const int Cx = src ? C2 : C1, coff = src ? C1 : 0;
+        const int nch = Cx >> 3;
+        const T* xbase = x + (long)n * H * W * Cx;
+        for (int c0 = 0; c0 < nch; c0 += 256) {
+            const int ncp = min(256, nch - c0);
+            const int lanes = 256 / ncp;
+            const int cc = tid % ncp, pl = tid / ncp;
+            if (pl >= lanes) continue;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = sc_sh[coff + (c0 + cc) * 8 + e];
+                sh[e] = sc_sh[C + coff + (c0 + cc) * 8 + e];
+            }
+            const T* xc = xbase + (c0 + cc) * 8;
+            T* yc = yb + coff + (c0 + cc) * 8;
+            auto srcp = [&](int pix) -> uint4 {
+                int sx = pix % Wo - pad;
+                const int sy = pix / Wo;
+                if (sx < 0) sx += W;
+                else if (sx >= W) sx -= W;
+                if constexpr (NTL) {
+                    const u32x4 r = __builtin_nontemporal_load((const u32x4*)(xc + ((long)sy * W + sx) * Cx));
+                    return uint4{r.x, r.y, r.z, r.w};
+                } else {
+                    return *(const uint4*)(xc + ((long)sy * W + sx) * Cx);
+                }
+            };
+            auto emit = [&](const uint4& raw, int pix) {
+                float f[8];
+                unpack8<T>(raw, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = f[e] * sc[e] + sh[e];
+                    f[e] = act ? silu_f(v) : v;
+                }
+                const uint4 o = pack8<T>(f);
+                if constexpr (NTS) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)(yc + (long)pix * C));
+                else *(uint4*)(yc + (long)pix * C) = o;
+            };
+            int pix = pix0 + pl;
+            for (; pix + (NLD - 1) * lanes < pix1; pix += NLD * lanes) {
+                uint4 r[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) r[i] = srcp(pix + i * lanes);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) emit(r[i], pix + i * lanes);
+            }
+            for (; pix < pix1; pix += lanes) emit(srcp(pix), pix);
+        }
     }
 }
 
@@ -554,9 +680,11 @@ extern "C" __attribute__((visibility("default"))) int im360_groupnorm_finalize(c
     IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_finalize: dtype %d unsupported", dtype);
     ProfScope prof(PROF_GN_STATS, stream);
     const double count = (double)pixels * (double)((C1 + C2) / G);
-    if (dtype == 0) hipLaunchKernelGGL((gn_finalize2_kernel<__bf16>), dim3((unsigned)(N * G)), dim3(64), 0, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
+    const size_t dyn = (size_t)(2 * (C1 + C2) + 2 * G) * sizeof(double);
+    IM360_CHECK_ARG(dyn <= 64 * 1024, "groupnorm_finalize: C=%ld too wide for the LDS work area", (long)(C1 + C2));
+    if (dtype == 0) hipLaunchKernelGGL((gn_finalize2_kernel<__bf16>), dim3((unsigned)N), dim3(256), dyn, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
                                        (const __bf16*)gamma, (const __bf16*)beta, (float*)scale, (float*)shift, (int)G, count, eps);
-    else hipLaunchKernelGGL((gn_finalize2_kernel<_Float16>), dim3((unsigned)(N * G)), dim3(64), 0, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
+    else hipLaunchKernelGGL((gn_finalize2_kernel<_Float16>), dim3((unsigned)N), dim3(256), dyn, (hipStream_t)stream, (const float*)pa, (int)Sa, (int)C1, (const float*)pb, (int)Sb, (int)C2,
                             (const _Float16*)gamma, (const _Float16*)beta, (float*)scale, (float*)shift, (int)G, count, eps);
     IM360_CHECK_LAUNCH();
     return IM360_OK;
@@ -616,6 +744,75 @@ extern "C" __attribute__((visibility("default"))) int im360_groupnorm_apply_cat(
     ProfScope prof(PROF_GN_APPLY, stream);
     if (dtype == 0) launch_gn_apply<__bf16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
     else launch_gn_apply<_Float16>(xa, xb, C1, C2, scale, shift, y, N, H, W, pad, act, (hipStream_t)stream);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// Per-slab partial sums with the circular-pad weighting of im360_groupnorm_stats (the `pad` wrapped columns count twice):
+// partial fp32 [N][S][2][C], S = im360_gn_num_slabs(N, H, W).  pad = 0: im360_groupnorm_partial.
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_partial_pad(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad,
+                                           int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(x && partial, "groupnorm_partial_pad: null pointer");
+    IM360_CHECK_ARG(N > 0 && N <= 65535 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "groupnorm_partial_pad: bad shape");
+    IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_partial_pad: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)x % 16) == 0, "groupnorm_partial_pad: misaligned x");
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_partial_pad: dtype %d unsupported", dtype);
+    ProfScope prof(PROF_GN_STATS, stream);
+    const int S = pick_slabs(N, H * W);
+    if (dtype == 0) hipLaunchKernelGGL((gn_partial_kernel<__bf16>), dim3(S, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S, (int)C, 0);
+    else hipLaunchKernelGGL((gn_partial_kernel<_Float16>), dim3(S, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (float*)partial, (int)(H * W), (int)W, (int)C, (int)pad, S, (int)C, 0);
+    IM360_CHECK_LAUNCH();
+    return IM360_OK;
+}
+
+// y [N, H, W + 2 pad, C1 + C2] = act(GroupNorm([xa | xb])) straight from PARTIAL SUMS: channels [0, C1) of the statistics from pa
+// ([N][Sa][2][C1]), [C1, C1 + C2) from pb ([N][Sb][2][C2]; xb / pb may be null with C2 = 0) -- written by im360_groupnorm_partial(_pad)
+// or by the epilogue of the kernel that produced the tensor (im360_conv_fwd / im360_linear_fwd, gn_partial).  One launch: no
+// finalize kernel, no scale / shift tensors (gn_apply_p_kernel).  Same bits as im360_groupnorm_finalize + im360_groupnorm_apply(_cat).
+// Replaces: InflatedGroupNorm / nn.GroupNorm (+ F.silu, + pad_pano), animatediff/models/resnet.py:9-17, 221-243; attention.py:206, 262;
+// motion_module.py:128, 169.
+extern "C" __attribute__((visibility("default"))) int im360_groupnorm_apply_partials(const void* xa, const void* xb, const void* pa, int64_t Sa, const void* pb, int64_t Sb,
+                                              const void* gamma, const void* beta, void* y, int64_t N, int64_t H, int64_t W, int64_t C1,
+                                              int64_t C2, int64_t G, int64_t pad, float eps, int act, int dtype, void* stream) {
+    using namespace im360;
+    IM360_CHECK_ARG(xa && pa && gamma && beta && y, "groupnorm_apply_partials: null pointer");
+    IM360_CHECK_ARG(N > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && G > 0 && Sa > 0 && (xb != nullptr) == (C2 > 0) && (pb != nullptr) == (C2 > 0) && (C2 == 0 || Sb > 0),
+                    "groupnorm_apply_partials: bad problem");
+    IM360_CHECK_ARG((C1 % 8) == 0 && (C2 % 8) == 0 && ((C1 + C2) % G) == 0, "groupnorm_apply_partials: C1=%ld, C2=%ld must be multiples of 8 and C1 + C2 of G=%ld", (long)C1, (long)C2, (long)G);
+    IM360_CHECK_ARG(pad >= 0 && 2 * pad <= W, "groupnorm_apply_partials: pad %ld out of range", (long)pad);
+    IM360_CHECK_ARG(((uintptr_t)xa % 16) == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)y % 16) == 0, "groupnorm_apply_partials: misaligned pointer");
+    IM360_CHECK_ARG(N <= 65535, "groupnorm_apply_partials: N=%ld exceeds grid.y", (long)N);
+    IM360_CHECK_ARG(dtype == 0 || dtype == 1, "groupnorm_apply_partials: dtype %d unsupported", dtype);
+    const int C = (int)(C1 + C2);
+    const size_t dyn = (size_t)(2 * C + 2 * G) * sizeof(double);
+    IM360_CHECK_ARG(dyn <= 64 * 1024, "groupnorm_apply_partials: C=%d too wide for the LDS work area", C);
+    ProfScope prof(PROF_GN_APPLY, stream);
+    const int S = pick_slabs(N, H * (W + 2 * pad));
+    // knob gn_apply: 0 = plain stores, 2 (default) = non-temporal stores (tools/ab_gn.py: - 2 ... - 22 % on the step's shapes, the
+    // output is hundreds of MB that the next kernel streams once), 1 / 3 = the same with eight loads in flight (ties), 6 = non-temporal loads too
+    const int v = knob(KNOB_GN_APPLY);
+    hipStream_t s = (hipStream_t)stream;
+#define IM360_GN_AP(T, NLD, NTS, NTL) hipLaunchKernelGGL((gn_apply_p_kernel<T, NLD, NTS, NTL>), dim3(S, (unsigned)N), dim3(256), dyn, s, (const T*)xa, (const T*)xb, (int)C1, (int)C2, \
+        (const float*)pa, (int)Sa, (const float*)pb, (int)Sb, (const T*)gamma, (const T*)beta, (T*)y, (int)H, (int)W, (int)G, (int)pad, act, S, eps)
+    if (dtype == 0) {
+        switch (v & 7) {
+            case 0: IM360_GN_AP(__bf16, 4, false, false); break;
+            case 1: IM360_GN_AP(__bf16, 8, false, false); break;
+            case 3: IM360_GN_AP(__bf16, 8, true, false); break;
+            case 6: IM360_GN_AP(__bf16, 4, true, true); break;
+            default: IM360_GN_AP(__bf16, 4, true, false); break;
+        }
+    } else {
+        switch (v & 7) {
+            case 0: IM360_GN_AP(_Float16, 4, false, false); break;
+            case 1: IM360_GN_AP(_Float16, 8, false, false); break;
+            case 3: IM360_GN_AP(_Float16, 8, true, false); break;
+            case 6: IM360_GN_AP(_Float16, 4, true, true); break;
+            default: IM360_GN_AP(_Float16, 4, true, false); break;
+        }
+    }
+#undef IM360_GN_AP
     IM360_CHECK_LAUNCH();
     return IM360_OK;
 }

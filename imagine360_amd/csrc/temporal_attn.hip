@@ -116,7 +116,9 @@ __global__ __launch_bounds__(512) void temporal_attn_lds_kernel(TAttnParams p, i
 }
 
 // ---- F <= 16: one workgroup (4 waves) = one (batch, pixel) x hpb heads
-template <typename T>
+// NT (knob tattn_nt; tools/ab_knob-style A/B in tools/ab_tattn.py): bit 0 = the output rows leave with non-temporal stores, bit 1 = q | k | v
+// arrive with non-temporal loads -- both streams are touched exactly once by this kernel.
+template <typename T, int NT = 0>
 __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TAttnParams p, int hpb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* rows = (T*)smem;                                 // [16 frames][q_g | k_g | v_g | 8 pad], g = this block's heads
@@ -136,7 +138,12 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TAttnParams p, 
             const T* base = seg == 0 ? (const T*)p.q + b * p.q_bs + px * p.q_ps + (long)f * p.q_fs
                           : seg == 1 ? (const T*)p.k + b * p.k_bs + px * p.k_ps + (long)f * p.k_fs
                                      : (const T*)p.v + b * p.v_bs + px * p.v_ps + (long)f * p.v_fs;
-            v = *(const uint4*)(base + h0 * d + ch * 8);
+            if constexpr ((NT & 2) != 0) {
+                const u32x4 r = __builtin_nontemporal_load((const u32x4*)(base + h0 * d + ch * 8));
+                v = make_uint4(r.x, r.y, r.z, r.w);
+            } else {
+                v = *(const uint4*)(base + h0 * d + ch * 8);
+            }
         }
         *(uint4*)(rows + f * pitch + seg * G + ch * 8) = v;
     }
@@ -194,9 +201,12 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(TAttnParams p, 
     // ---- whole token rows out
     for (int c = tid; c < 16 * cps; c += 256) {
         const int ch = c % cps, f = c / cps;
-        if (f < F)
-            *(uint4*)((T*)p.out + b * p.o_bs + px * p.o_ps + (long)f * p.o_fs + h0 * d + ch * 8) =
-                *(const uint4*)(rows + f * pitch + ch * 8);
+        if (f < F) {
+            const uint4 w = *(const uint4*)(rows + f * pitch + ch * 8);
+            T* dst = (T*)p.out + b * p.o_bs + px * p.o_ps + (long)f * p.o_fs + h0 * d + ch * 8;
+            if constexpr ((NT & 1) != 0) __builtin_nontemporal_store(u32x4{w.x, w.y, w.z, w.w}, (u32x4*)dst);
+            else *(uint4*)dst = w;
+        }
     }
 }
 
@@ -328,7 +338,12 @@ static int launch_tattn(const TAttnParams& p, hipStream_t stream) {
         if (lds <= 64 * 1024) {
             const long npix = p.total / ((long)p.F * p.heads);
             dim3 grid((unsigned)npix, (unsigned)(p.heads / hpb));
-            hipLaunchKernelGGL((temporal_attn_mfma_kernel<T>), grid, dim3(256), lds, stream, p, hpb);
+            switch (knob(KNOB_TATTN_NT) & 3) {
+                case 1: hipLaunchKernelGGL((temporal_attn_mfma_kernel<T, 1>), grid, dim3(256), lds, stream, p, hpb); break;
+                case 2: hipLaunchKernelGGL((temporal_attn_mfma_kernel<T, 2>), grid, dim3(256), lds, stream, p, hpb); break;
+                case 3: hipLaunchKernelGGL((temporal_attn_mfma_kernel<T, 3>), grid, dim3(256), lds, stream, p, hpb); break;
+                default: hipLaunchKernelGGL((temporal_attn_mfma_kernel<T, 0>), grid, dim3(256), lds, stream, p, hpb); break;
+            }
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }

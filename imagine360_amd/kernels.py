@@ -38,6 +38,8 @@ _SIGNATURES = {
     "im360_conv_gn_slabs": (_I64, [_I64] * 6),
     "im360_groupnorm_partial": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_groupnorm_finalize": (_INT, [_PTR, _I64, _I64, _PTR, _I64, _I64] + [_PTR] * 4 + [_I64] * 3 + [_F32, _INT, _PTR]),
+    "im360_groupnorm_partial_pad": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
+    "im360_groupnorm_apply_partials": (_INT, [_PTR, _PTR, _PTR, _I64, _PTR, _I64, _PTR, _PTR, _PTR] + [_I64] * 7 + [_F32, _INT, _INT, _PTR]),
     "im360_pack_conv_weight": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
     "im360_attn_pack_bias": (_INT, [_PTR] * 2 + [_I64, _INT, _PTR]),
     "im360_conv_up2_fwd": (_INT, [_PTR] * 4 + [_I64] * 6 + [_INT, _PTR]),
@@ -55,7 +57,7 @@ _SIGNATURES = {
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
-ABI_VERSION = 3          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
+ABI_VERSION = 4          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
 
 PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
 
@@ -388,9 +390,48 @@ def group_norm_apply(x, scale, shift, silu, pad=0):
 GN_FUSED = False
 
 
+def group_norm_partials(x, pad=0):
+    """Per-image partial sums of x [N, H, W, C] as (buffer fp32 [N][S][2][C], S): the ones the tensor's producer wrote in its
+    epilogue (pad == 0 only: the padded statistics weight the wrapped columns twice), else one statistics pass over x."""
+    g = _gn_of(x) if (pad == 0 and GN_FROM_PRODUCER) else None
+    if g is not None:
+        return g
+    N, H, W, C = x.shape
+    assert x.is_contiguous()
+    S = lib().im360_gn_num_slabs(N, H, W)
+    buf = torch.empty((N * S * 2 * C,), dtype=torch.float32, device=x.device)
+    if pad:
+        _check(lib().im360_groupnorm_partial_pad(_p(x), _p(buf), N, H, W, C, pad, _dt(x), _stream()), "im360_groupnorm_partial_pad")
+    else:
+        _check(lib().im360_groupnorm_partial(_p(x), _p(buf), N, H, W, C, _dt(x), _stream()), "im360_groupnorm_partial")
+    _count("gn_stats", 0.0, x.element_size() * x.numel() + 4 * buf.numel())
+    return buf, S
+
+
+# group_norm(): "partials" (default since round 6) = statistics pass only where the producer did not leave partial sums, then ONE
+# launch that rebuilds scale / shift per workgroup and normalises (im360_groupnorm_apply_partials: no finalize launch, the
+# concatenation in one launch instead of two); "three" = rounds 2 - 5's statistics + finalize + apply (same bits; the A/B partner);
+# GN_FUSED below = the single-launch variant with arrival counters (measured slower).
+GN_MODE = os.environ.get("IM360_GN_MODE", "partials")
+
+
 def group_norm(x, gamma, beta, groups, eps, silu=False, pad=0):
-    """act(GroupNorm(x)) [N, H, W + 2 pad, C]; x [N, H, W, C] or a pair standing for a channel concatenation: statistics
-    kernel + finalize + apply (or, with ``GN_FUSED``, the single-launch variant -- see the note at the flag)."""
+    """act(GroupNorm(x)) [N, H, W + 2 pad, C]; x [N, H, W, C] or a pair standing for a channel concatenation (see GN_MODE)."""
+    if not GN_FUSED and GN_MODE == "partials":
+        xa, xb = x if isinstance(x, (tuple, list)) else (x, None)
+        _dev(xa, xb, gamma, beta)
+        N, H, W, C1 = xa.shape
+        C2 = xb.shape[-1] if xb is not None else 0
+        assert xa.is_contiguous() and gamma.dtype == xa.dtype and beta.dtype == xa.dtype and gamma.numel() == C1 + C2
+        assert xb is None or (xb.is_contiguous() and xb.shape[:3] == xa.shape[:3] and xb.dtype == xa.dtype)
+        pa, Sa = group_norm_partials(xa, pad)
+        pb, Sb = group_norm_partials(xb, pad) if xb is not None else (None, 0)
+        y = torch.empty((N, H, W + 2 * pad, C1 + C2), dtype=xa.dtype, device=xa.device)
+        rc = lib().im360_groupnorm_apply_partials(_p(xa), _p(xb), _p(pa), Sa, _p(pb), Sb, _p(gamma), _p(beta), _p(y), N, H, W, C1, C2,
+                                                  groups, pad, float(eps), int(bool(silu)), _dt(xa), _stream())
+        _check(rc, "im360_groupnorm_apply_partials")
+        _count("gn_apply", 0.0, xa.element_size() * (N * H * W * (C1 + C2) + y.numel()))
+        return y
     if not GN_FUSED:
         scale, shift = group_norm_stats(x, gamma, beta, groups, eps, pad)
         return group_norm_apply(x, scale, shift, silu, pad)
@@ -788,7 +829,7 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
 
 # ------------------------------------------------------------------------------------------ tuning knobs
 KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9,
-         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20}
+         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20, "gn_apply": 21, "tattn_nt": 22, "nt": 23, "g4": 24}
 
 
 ATTN_PIPE_DEFAULT = -1         # the library's default for the attn_pipe knob (abi.cpp)

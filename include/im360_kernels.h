@@ -16,7 +16,8 @@
 extern "C" {
 #endif
 
-/* 2 since round 5: im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer and the table rows of
+/* 4 since round 6 (3: packed-bias block maps of im360_attn_fwd; 4: im360_groupnorm_partial_pad / im360_groupnorm_apply_partials added).
+ * 2 since round 5: im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer and the table rows of
  * im360_linear_ln_fwd include c2 (both introduced in round 4 under version 1).  imagine360_amd/kernels.py refuses a mismatch. */
 int im360_abi_version(void);
 /* bit 0: ablation build (`make ablate`): the rejected A/B kernel variants behind the attn_dbg / attn_hl / attn_hg / attn_ds knobs exist */
@@ -112,6 +113,20 @@ int im360_groupnorm_finalize(const void* pa, int64_t Sa, int64_t C1, const void*
 int im360_groupnorm_apply(const void* x, const void* scale, const void* shift, void* y,
                           int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int act,
                           int dtype, void* stream);
+
+/* Round 6 (ABI version 4) -- the normalisation straight from PARTIAL SUMS, one launch: no finalize kernel, no scale / shift tensors.
+ * im360_groupnorm_partial_pad: im360_groupnorm_partial with the circular-pad weighting of im360_groupnorm_stats (the `pad` wrapped
+ *   columns count twice; src/models/MVGenModel.py:277-278).
+ * im360_groupnorm_apply_partials: y [N, H, W + 2 pad, C1 + C2] = act(GroupNorm([xa | xb])); the statistics of channels [0, C1)
+ *   come from pa ([N][Sa][2][C1]), those of [C1, C1 + C2) from pb ([N][Sb][2][C2]); xb / pb null with C2 = 0.  Every workgroup
+ *   rebuilds scale / shift of its image from the partial sums (the reduction order, and the bits, of im360_groupnorm_finalize).
+ * Replaces: InflatedGroupNorm / nn.GroupNorm (+ F.silu, + pad_pano, + torch.cat([x, skip])), animatediff/models/resnet.py:9-17,
+ *   221-243; animatediff/models/attention.py:206, 262; motion_module.py:128, 169; src/models/MVGenModel.py:407-437. */
+int im360_groupnorm_partial_pad(const void* x, void* partial, int64_t N, int64_t H, int64_t W, int64_t C, int64_t pad, int dtype,
+                                void* stream);
+int im360_groupnorm_apply_partials(const void* xa, const void* xb, const void* pa, int64_t Sa, const void* pb, int64_t Sb,
+                                   const void* gamma, const void* beta, void* y, int64_t N, int64_t H, int64_t W, int64_t C1,
+                                   int64_t C2, int64_t G, int64_t pad, float eps, int act, int dtype, void* stream);
 
 /* The two GroupNorm passes on the channel concatenation [xa | xb] (xa [N, H, W, C1], xb [N, H, W, C2]) WITHOUT
  * materialising it: gamma / beta / scale / shift / y span C1 + C2 channels, partial holds N * S * 2 * (C1 + C2) floats.

@@ -42,7 +42,7 @@ def q16(t, dt):
 
 
 def test_library_loads():
-    assert K.lib().im360_abi_version() == K.ABI_VERSION == 3
+    assert K.lib().im360_abi_version() == K.ABI_VERSION == 4
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -1048,6 +1048,73 @@ def test_group_norm_single_launch_equals_the_three_kernel_path(dt, N, H, W, C1, 
             assert got.shape == (N, H, W + 2 * pad, C) and torch.equal(got, want)
     finally:
         K.GN_FUSED = False
+
+
+# ------------------------------------------------------------------ round 6: normalisation straight from the partial sums
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C1,C2,pad,silu", [(3, 8, 16, 64, 0, 0, True), (2, 16, 32, 320, 0, 2, True), (5, 4, 4, 1280, 0, 0, False), (1, 64, 128, 320, 0, 2, True),
+                                                   (2, 16, 32, 640, 320, 2, True), (4, 8, 8, 1280, 640, 0, False), (2, 6, 10, 320, 320, 2, True), (40, 32, 32, 320, 0, 0, True)])
+def test_group_norm_from_partial_sums_equals_the_three_launch_path(dt, N, H, W, C1, C2, pad, silu):
+    """im360_groupnorm_apply_partials (every workgroup rebuilds its image's scale / shift from the partial sums, then normalises:
+    ONE launch behind the statistics) == statistics + finalize + apply, bit for bit on one tensor (the same reduction order), to
+    the fp64 order of a group that straddles the two tensors of a pair (30 channels per group at 960); and against fp32 torch."""
+    xa = q16(rnd(N, H, W, C1, seed=160) + 0.3, dt).to(dt).cuda()
+    xb = q16(rnd(N, H, W, C2, seed=161) * 1.5, dt).to(dt).cuda() if C2 else None
+    C = C1 + C2
+    gamma, beta = (1 + 0.1 * rnd(C, seed=162)).to(dt).cuda(), (0.1 * rnd(C, seed=163)).to(dt).cuda()
+    x = xa if xb is None else (xa, xb)
+    assert K.GN_MODE == "partials"
+    got = K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad)
+    try:
+        K.GN_MODE = "three"
+        want = K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad)
+    finally:
+        K.GN_MODE = "partials"
+    assert got.shape == want.shape == (N, H, W + 2 * pad, C)
+    if xb is None:
+        assert torch.equal(got, want)
+    else:
+        assert rel(got, want) < 1e-6 and (got.float() - want.float()).abs().max() <= 2 * float(want.float().abs().max()) * 2.0 ** (-8 if dt == torch.bfloat16 else -11)
+    cat = xa if xb is None else torch.cat([xa, xb], dim=-1)
+    ref = F.group_norm(OG.pad_pano(cat.float().cpu().permute(0, 3, 1, 2), pad), 32, gamma.float().cpu(), beta.float().cpu(), 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
+    assert rel(got, ref) < TOL[dt]
+    for v in (0, 1, 3, 6):                  # the A/B variants of the apply loop (plain stores, loads in flight, non-temporal loads): the same bits
+        try:
+            K.tuning_set("gn_apply", v)
+            assert torch.equal(K.group_norm(x, gamma, beta, 32, 1e-5, silu=silu, pad=pad), got)
+        finally:
+            K.tuning_set("gn_apply", 2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_group_norm_from_the_producers_partial_sums_in_one_launch(dt):
+    """The tagged output of conv2d(..., gn_stats=True) normalised by ONE launch (no statistics pass, no finalize) == the
+    finalize + apply pair on the same partial sums, bit for bit; a pair of one tagged and one untagged tensor likewise to fp64 order."""
+    g = torch.Generator().manual_seed(164)
+    N, H, W, Cin, Cout = 160, 32, 32, 320, 320
+    x = torch.randn(N, H, W, Cin, generator=g).to(dt).cuda()
+    wp = K.pack_conv_weight((torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(dt).cuda())
+    y = K.conv2d(x, wp, Cout, gn_stats=True)
+    assert K._gn_of(y) is not None
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).to(dt).cuda(), (0.1 * torch.randn(Cout, generator=g)).to(dt).cuda()
+    K.STATS = {}
+    try:
+        got = K.group_norm(y, gamma, beta, 32, 1e-5, silu=True)
+        assert "gn_stats" not in K.STATS and K.STATS["gn_apply"][2] == 1          # one launch, no statistics launch
+    finally:
+        K.STATS = None
+    try:
+        K.GN_MODE = "three"
+        want = K.group_norm(y, gamma, beta, 32, 1e-5, silu=True)
+    finally:
+        K.GN_MODE = "partials"
+    assert torch.equal(got, want)
+    skip = torch.randn(N, H, W, 640, generator=g).to(dt).cuda()
+    g2, b2 = (1 + 0.1 * torch.randn(960, generator=g)).to(dt).cuda(), (0.1 * torch.randn(960, generator=g)).to(dt).cuda()
+    got = K.group_norm((y, skip), g2, b2, 32, 1e-5, silu=True)
+    ref = F.silu(F.group_norm(torch.cat([y, skip], dim=-1).float().cpu().permute(0, 3, 1, 2), 32, g2.float().cpu(), b2.float().cpu(), 1e-5)).permute(0, 2, 3, 1)
+    assert rel(got, ref) < TOL[dt]
 
 
 # ------------------------------------------------------------------ round 4: GroupNorm statistics from the producer's epilogue

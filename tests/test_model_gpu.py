@@ -858,8 +858,9 @@ def test_warp_attn_block_at_cfg5_level_1_size_vs_oracle():
         obs[f"{tag}_equi_worst_block"] = float(((ge.float().cpu() - oe[:, :, 0].permute(0, 2, 3, 1)).reshape(-1, 32, c).norm(dim=(1, 2))
                                                 / oe[:, :, 0].permute(0, 2, 3, 1).reshape(-1, 32, c).norm(dim=(1, 2))).max())
     _record("warp_attn_block_64x128x32", **obs)
-    assert max(v for k, v in obs.items() if not k.endswith("worst_block")) < 4e-3, obs
-    assert max(v for k, v in obs.items() if k.endswith("worst_block")) < 1.6e-2, obs
+    # observed on MI355X: 4.4e-4 everywhere (tensor and worst 32-row block): the bounds are 3 x that, not a tolerance picked by hand
+    assert max(v for k, v in obs.items() if not k.endswith("worst_block")) < 1.3e-3, obs
+    assert max(v for k, v in obs.items() if k.endswith("worst_block")) < 1.5e-3, obs
 
 
 def test_preprocessing_warps_vs_oracle():
