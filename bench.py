@@ -357,7 +357,8 @@ def main(argv=None):
         if not plumbing:
             torch.cuda.synchronize()
 
-    prof_kinds = ["conv", "gemm", "attn", "temporal", "gn_stats", "gn_apply", "misc"]
+    # (attn_warp / attn_x2: the biased WarpAttn launches and the two-set text + IP cross attention, timed apart and merged into "attn" below)
+    prof_kinds = ["conv", "gemm", "attn", "attn_warp", "attn_x2", "temporal", "gn_stats", "gn_apply", "misc"]
     graphed = None
     if not args.no_graph and (shard is None or os.environ.get("IM360_GRAPH_SHARDED", "1") != "0"):
         # the step is ~3000 launches (+ 128 all-to-alls in the frame modes): capture it once (hipGraph) and replay, so the
@@ -508,6 +509,15 @@ def main(argv=None):
                                         "the timed region the panorama branch's kernels run beside the perspective branch's (side stream): "
                                         "the per-class durations therefore add up to more than ms_per_step" if was_dual else ""))
             classes = {}
+            # the attention class = all three kinds of launches, as in every earlier round; the parts are kept for the breakdown below
+            attn_parts = {}
+            for sub in ("attn", "attn_warp", "attn_x2"):
+                attn_parts[sub] = (prof.get(sub, (0.0, 0)), list(stats.get(sub, [0.0, 0.0, 0, 0.0])))
+            prof["attn"] = (sum(v[0][0] for v in attn_parts.values()), sum(v[0][1] for v in attn_parts.values()))
+            stats["attn"] = [sum(v[1][i] for v in attn_parts.values()) for i in range(4)]
+            for sub in ("attn_warp", "attn_x2"):
+                prof.pop(sub, None)
+                stats.pop(sub, None)
             for kname, (ms, n) in prof.items():
                 fl, by, _, fx = stats.get(kname, [0.0, 0.0, 0, 0.0])
                 t = ms * 1e-3
@@ -584,6 +594,25 @@ def main(argv=None):
                                 "frac": a.get("frac_of_mfma_peak", 0.0),
                                 "algorithmic_tflop_per_step": a["algorithmic_tflop_per_step"],
                                 "note": "QK^T + PV flops of every attn_fwd launch (self, text + IP cross, WarpAttn) over their summed time"}
+            # the same, by kind of launch: the two-set text + IP cross attention (77 + 64 keys, K / V resident in LDS) streams Q and O and
+            # is bound by HBM, not by the matrix pipe -- its own roofline is the HBM one; `mfma_bound_kinds` leaves it out
+            by_kind = {}
+            for sub, label in (("attn", "self + single-set cross attention (d = 64)"), ("attn_warp", "WarpAttn cross-view attention (d = 32, shared soft mask)"),
+                               ("attn_x2", "text + IP-adapter cross attention (two key / value sets, 77 + 64 keys)")):
+                (ms, n), (fl, by, _, fx) = attn_parts[sub]
+                if n:
+                    t = ms * 1e-3
+                    by_kind[sub] = {"what": label, "ms_per_step": ms / args.steps, "launches_per_step": n / args.steps,
+                                    "tflops": fl / t / 1e12, "frac_of_mfma_peak": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                                    "gbs": by / t / 1e9, "frac_of_hbm_peak": by / t / 1e9 / HBM_PEAK_GBS,
+                                    "bound": "mfma" if fl / (MFMA_PEAK_TFLOPS * 1e12) >= by / (HBM_PEAK_GBS * 1e9) else "hbm"}
+            out["attention"]["by_kind"] = by_kind
+            mf = [attn_parts[k] for k in ("attn", "attn_warp") if attn_parts[k][0][1]]
+            if mf:
+                t = sum(v[0][0] for v in mf) * 1e-3
+                fl = sum(v[1][0] for v in mf)
+                out["attention"]["mfma_bound_kinds"] = {"tflops": fl / t / 1e12, "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                                                        "note": "self + WarpAttn launches only (the kinds whose roofline is the matrix pipe); `frac` above stays the figure over ALL launches"}
         if world == 1 and args.cpu_baseline != "none":
             if args.cpu_baseline == "sample":
                 out["cpu_baseline"] = cpu_baseline_sample(args)

@@ -106,7 +106,7 @@ struct Knobs {
             {im360::KNOB_CONV_BK, "IM360_CONV_BK", 0},       {im360::KNOB_TATTN_SCALAR, "IM360_TATTN_SCALAR", 0},
             {im360::KNOB_CONV_RING, "IM360_CONV_RING", 1},    {im360::KNOB_CONV_HALO, "IM360_CONV_HALO", 0},
             {im360::KNOB_CONV_CM, "IM360_CONV_CM", 1},        {im360::KNOB_LN_PACKED, "IM360_LN_PACKED", 1},
-            {im360::KNOB_RING_GROUPS, "IM360_RING_GROUPS", 0}, {im360::KNOB_ATTN_X, "IM360_ATTN_X", 3}, {im360::KNOB_ATTN_DS, "IM360_ATTN_DS", 0}, {im360::KNOB_ATTN_ONE, "IM360_ATTN_ONE", 1}, {im360::KNOB_ATTN_HG, "IM360_ATTN_HG", 0}, {im360::KNOB_CONV_SMALL, "IM360_CONV_SMALL", 2}, {im360::KNOB_ATTN_W3, "IM360_ATTN_W3", 1}, {im360::KNOB_ATTN_PIPE, "IM360_ATTN_PIPE", -1}, {im360::KNOB_CONV_STAG, "IM360_CONV_STAG", 0}, {im360::KNOB_CONV_PERSIST, "IM360_CONV_PERSIST", 0}, {im360::KNOB_GN_APPLY, "IM360_GN_APPLY", 2}, {im360::KNOB_TATTN_NT, "IM360_TATTN_NT", 0}, {im360::KNOB_NT, "IM360_NT", 1}, {im360::KNOB_G4, "IM360_G4", 0},
+            {im360::KNOB_RING_GROUPS, "IM360_RING_GROUPS", 0}, {im360::KNOB_ATTN_X, "IM360_ATTN_X", 3}, {im360::KNOB_ATTN_DS, "IM360_ATTN_DS", 0}, {im360::KNOB_ATTN_ONE, "IM360_ATTN_ONE", 1}, {im360::KNOB_ATTN_HG, "IM360_ATTN_HG", 0}, {im360::KNOB_CONV_SMALL, "IM360_CONV_SMALL", 2}, {im360::KNOB_ATTN_W3, "IM360_ATTN_W3", 1}, {im360::KNOB_ATTN_PIPE, "IM360_ATTN_PIPE", -1}, {im360::KNOB_CONV_STAG, "IM360_CONV_STAG", 0}, {im360::KNOB_CONV_PERSIST, "IM360_CONV_PERSIST", 0}, {im360::KNOB_GN_APPLY, "IM360_GN_APPLY", 2}, {im360::KNOB_TATTN_NT, "IM360_TATTN_NT", 0}, {im360::KNOB_NT, "IM360_NT", 1}, {im360::KNOB_G4, "IM360_G4", 0}, {im360::KNOB_GN_WGS, "IM360_GN_WGS", 0},
         };
         for (auto& x : v) x.store(0);
         for (auto& i : init) {

@@ -1093,7 +1093,7 @@ extern "C" __attribute__((visibility("default"))) int im360_attn_fwd(const void*
     p.k2 = nullptr; p.v2 = nullptr; p.Nk2 = 0; p.k2_bs = p.k2_rs = p.v2_bs = p.v2_rs = 0; p.out_scale2 = 0.f;
     p.x_nqb = p.x_bpp = 0; p.x_total = 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(PROF_ATTN, stream);
+    ProfScope prof(bias ? PROF_ATTN_WARP : PROF_ATTN, stream);
     if (dtype == 0) return D == 64 ? launch_attn<__bf16, 64>(p, s) : launch_attn<__bf16, 32>(p, s);
     if (dtype == 1) return D == 64 ? launch_attn<_Float16, 64>(p, s) : launch_attn<_Float16, 32>(p, s);
     im360_set_error("attn_fwd: dtype %d unsupported (0=bf16, 1=f16)", dtype);
@@ -1127,7 +1127,7 @@ extern "C" __attribute__((visibility("default"))) int im360_attn_fwd2(const void
     p.k2 = k2; p.v2 = v2; p.Nk2 = (int)Nk2; p.k2_bs = k2_bs; p.k2_rs = k2_rs; p.v2_bs = v2_bs; p.v2_rs = v2_rs; p.out_scale2 = out_scale2;
     p.x_nqb = p.x_bpp = 0; p.x_total = 0;
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(PROF_ATTN, stream);
+    ProfScope prof(PROF_ATTN_X2, stream);
     if (dtype == 0) return launch_attn<__bf16, 64>(p, s);
     if (dtype == 1) return launch_attn<_Float16, 64>(p, s);
     im360_set_error("attn_fwd2: dtype %d unsupported (0=bf16, 1=f16)", dtype);

@@ -57,8 +57,9 @@ struct ConvParams {
     // when an image is a whole number of tiles (H W % 256 == 0: slab s of image n = tile n * (H W / 256) + s), so the consumer's
     // GroupNorm skips its own statistics pass over the tensor (animatediff/models/resnet.py:221-243: norm -> act -> conv, twice)
     float* gn_out;
-    // knob nt bit 0 (A/B): the epilogue's output rows leave with non-temporal stores (the tensors are hundreds of MB that the next
-    // kernel streams once)
+    // knob nt (default 1; tools/ab_step.py, profiles/r06_step_knobs_ab.log: - 1.5 ms per cfg2 step): the epilogue's output rows leave with
+    // non-temporal stores -- tensors of hundreds of MB that should not push the operands out of the L2.  (The same on the attention
+    // outputs, which the out-projection reads back at once, cost + 6.7 ms; on the LayerNorm / GEGLU element-wise kernels nothing.)
     int nt_store;
 };
 
@@ -1987,7 +1988,7 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_geglu(const v
     // the four-wave register-staged tile: knob g4 bit 0 (or, A/B tools, conv_ring 12)
     if (((knob(KNOB_G4) & 1) || knob(KNOB_CONV_RING) == 12) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)
         return dtype == 0 ? launch_g4_t<__bf16, 1>(p, s) : launch_g4_t<_Float16, 1>(p, s);
-    if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)       // the same loop, two workgroups per CU (256 x 128 tiles)
+    if (((knob(KNOB_G4) & 4) || knob(KNOB_CONV_RING) == 13) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)       // the same loop, two workgroups per CU (256 x 128 tiles): knob g4 bit 2
         return dtype == 0 ? launch_g4b_t<__bf16, 1>(p, s) : launch_g4b_t<_Float16, 1>(p, s);
     if (knob(KNOB_CONV_RING) && ((M + 255) / 256) * (2 * I / 256) >= 512) {
         const int v = knob(KNOB_CONV_RING) == 5 ? 1 : (knob(KNOB_CONV_RING) == 7 ? 6 : knob(KNOB_CONV_RING));      // (5 / 7: the ring kernel for the convolutions too)
@@ -2107,7 +2108,7 @@ extern "C" __attribute__((visibility("default"))) int im360_linear_geglu_ln(cons
     ProfScope prof(PROF_GEMM, stream);
     if (((knob(KNOB_G4) & 2) || knob(KNOB_CONV_RING) == 12) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && ((2 * I) % 256) == 0 && (M / 256) * (2 * I / 256) >= 256)       // knob g4 bit 1
         return dtype == 0 ? launch_g4_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4_t<_Float16, 4>(p, (hipStream_t)stream);
-    if (knob(KNOB_CONV_RING) == 13 && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)
+    if (((knob(KNOB_G4) & 8) || knob(KNOB_CONV_RING) == 13) && (K % 64) == 0 && K >= 128 && (M % 256) == 0 && (M / 256) * (2 * I / 128) >= 512)       // knob g4 bit 3
         return dtype == 0 ? launch_g4b_t<__bf16, 4>(p, (hipStream_t)stream) : launch_g4b_t<_Float16, 4>(p, (hipStream_t)stream);
     const int v6 = (knob(KNOB_CONV_RING) == 8 || knob(KNOB_CONV_RING) == 10 || knob(KNOB_CONV_RING) == 11) ? knob(KNOB_CONV_RING) : 1;
     return dtype == 0 ? launch_ring_t<__bf16, 4, 4, true>(p, (hipStream_t)stream, v6) : launch_ring_t<_Float16, 4, 4, true>(p, (hipStream_t)stream, v6);

@@ -520,9 +520,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int ctile = tile_first;
     for (int t = 0; t < my_tiles; ++t) {
+        __builtin_amdgcn_s_setprio(1);            // the K loop's MFMAs go first; the other workgroup's epilogue fills the vector slots between them
+                                                  // (a start skew between the CU's two workgroups changes nothing: profiles/r06_g4b_phase_skew.log)
         stage(MFirst{});
         for (int k = 2; k < nph; ++k) stage(MMid{});
         stage(MLast{});
+        __builtin_amdgcn_s_setprio(0);
         // ---- epilogue: empty queue, no register in flight; the accumulators are cleared by tile_epilogue (ZACC)
         const long m0 = tile_m0(ctile);
         const int n0 = tile_n0(ctile);

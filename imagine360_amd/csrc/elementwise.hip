@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void layernorm_packed_kernel(const T* __restri
 
 // h [rows, 2*I] = (a | gate) -> out [rows, I] = a * gelu(gate), exact (erf) GELU
 template <typename T>
-__global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8, int nt) {
+__global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8) {
     const long total = rows * I8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / I8;
@@ -205,9 +205,7 @@ __global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long 
         unpack8<T>(hr[I8 + c], g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] *= 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f));
-        const uint4 o = pack8<T>(a);
-        if (nt) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)out + i);      // (knob nt bit 3)
-        else ((uint4*)out)[i] = o;
+        ((uint4*)out)[i] = pack8<T>(a);
     }
 }
 
@@ -369,9 +367,9 @@ extern "C" __attribute__((visibility("default"))) int im360_geglu(const void* h,
     ProfScope prof(PROF_MISC, stream);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
-        hipLaunchKernelGGL((geglu_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)h, (__bf16*)out, (long)rows, (int)(I / 8), (knob(KNOB_NT) >> 3) & 1);
+        hipLaunchKernelGGL((geglu_kernel<__bf16>), dim3(blocks), dim3(256), 0, s, (const __bf16*)h, (__bf16*)out, (long)rows, (int)(I / 8));
     else if (dtype == 1)
-        hipLaunchKernelGGL((geglu_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)h, (_Float16*)out, (long)rows, (int)(I / 8), (knob(KNOB_NT) >> 3) & 1);
+        hipLaunchKernelGGL((geglu_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, (const _Float16*)h, (_Float16*)out, (long)rows, (int)(I / 8));
     else {
         im360_set_error("geglu: dtype %d unsupported", dtype);
         return IM360_ERR_UNSUPPORTED;

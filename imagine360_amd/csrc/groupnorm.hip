@@ -788,7 +788,14 @@ extern "C" __attribute__((visibility("default"))) int im360_groupnorm_apply_part
     const size_t dyn = (size_t)(2 * C + 2 * G) * sizeof(double);
     IM360_CHECK_ARG(dyn <= 64 * 1024, "groupnorm_apply_partials: C=%d too wide for the LDS work area", C);
     ProfScope prof(PROF_GN_APPLY, stream);
-    const int S = pick_slabs(N, H * (W + 2 * pad));
+    // slabs per image: every workgroup repeats the image's reduction in front of its slab, so fewer, larger slabs than the statistics
+    // kernel's (knob gn_wgs = target number of workgroups; 0 = pick_slabs' 2048)
+    int S = pick_slabs(N, H * (W + 2 * pad));
+    if (const int tgt = knob(KNOB_GN_WGS); tgt > 0) {
+        long s2 = (tgt + N - 1) / N;
+        if (s2 < 1) s2 = 1;
+        if (s2 < S) S = (int)s2;
+    }
     // knob gn_apply: 0 = plain stores, 2 (default) = non-temporal stores (tools/ab_gn.py: - 2 ... - 22 % on the step's shapes, the
     // output is hundreds of MB that the next kernel streams once), 1 / 3 = the same with eight loads in flight (ties), 6 = non-temporal loads too
     const int v = knob(KNOB_GN_APPLY);

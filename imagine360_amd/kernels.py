@@ -59,7 +59,7 @@ _SIGNATURES = {
 
 ABI_VERSION = 4          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
 
-PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6}
+PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6, "attn_warp": 7, "attn_x2": 8}
 
 
 # Algorithmic work of the launches, by class (bench.py's roofline legs): None = off, else {class: [flops, bytes, launches]}
@@ -209,7 +209,7 @@ def attention(q, k, v, heads, scale=None, bias=None, out=None, accumulate=False,
                               float(scale), float(out_scale), int(accumulate), _dt(q) + (256 if bias_packed else 0), _stream(), _p(bias_alt), _p(bias_sel),
                               _p(bias_blocks), _p(bias_blocks_alt), bias_blocks.shape[1] if bias_blocks is not None else 0)
     _check(rc, "im360_attn_fwd")
-    _count("attn", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
+    _count("attn" if bias is None else "attn_warp", 4.0 * B * heads * Nq * Nk * d, q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * Nk * C)
            + (0 if bias is None else bias.element_size() * Nq * Nk))
     return out
 
@@ -232,7 +232,7 @@ def attention2(q, k, v, k2, v2, heads, scale=None, out_scale=1.0, out_scale2=1.0
                                k2.stride(0), k2.stride(1), v2.stride(0), v2.stride(1), out.stride(0), out.stride(1),
                                kv_group, float(scale), float(out_scale), float(out_scale2), _dt(q), _stream())
     _check(rc, "im360_attn_fwd2")
-    _count("attn", 4.0 * B * heads * Nq * (k.shape[1] + k2.shape[1]) * d,
+    _count("attn_x2", 4.0 * B * heads * Nq * (k.shape[1] + k2.shape[1]) * d,
            q.element_size() * (2 * B * Nq * C + 2 * k.shape[0] * (k.shape[1] + k2.shape[1]) * C))
     return out
 
@@ -829,7 +829,7 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
 
 # ------------------------------------------------------------------------------------------ tuning knobs
 KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9,
-         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20, "gn_apply": 21, "tattn_nt": 22, "nt": 23, "g4": 24}
+         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20, "gn_apply": 21, "tattn_nt": 22, "nt": 23, "g4": 24, "gn_wgs": 25}
 
 
 ATTN_PIPE_DEFAULT = -1         # the library's default for the attn_pipe knob (abi.cpp)
