@@ -119,7 +119,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
     int set_nk = p.Nk;
     const T* bias = (const T*)p.bias;
     const uint32_t* blk = p.bias_blocks;
-    if (HAS_BIAS && p.bias_sel != nullptr && __builtin_nontemporal_load(p.bias_sel) != 0) {
+    // (readfirstlane: the selector and, below, the map words are wave-uniform -- as scalars the block decisions are s_cbranch on SGPR bits;
+    //  left to hipcc they were VGPR words spilled to scratch and tested with v_cmp / exec masks every tile)
+    if (HAS_BIAS && p.bias_sel != nullptr && __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(p.bias_sel)) != 0) {
         bias = (const T*)p.bias_alt;
         blk = p.bias_blocks_alt;
     }
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         const int r = qblk + qb < nqblk ? qblk + qb : nqblk - 1;
         return w < p.blocks_rs ? __builtin_nontemporal_load(blk + (long)r * p.blocks_rs + w) : 0u;
     };
-    // bit qb of the result: block qb of this wave needs the bias of 32-key half `h`
+    // bit qb of the result: block qb of this wave needs the bias of 32-key half `h` (readfirstlane: the bits are wave-uniform; as a
+    // scalar the decisions below are s_cbranch on SGPR bits instead of v_cmp + exec-mask regions)
     auto blk_need = [&](int h, int t) -> unsigned {
         if (!use_blk) return (1u << QB) - 1u;
         unsigned m = 0;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
             const uint32_t w = (h >> 5) == (t >> 4) ? blkw[qb] : blkn[qb];
             m |= ((w >> (h & 31)) & 1u) << qb;
         }
-        return m;
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     };
     auto fetch_half = [&](int key_base, auto bufc, unsigned need = ~0u) {
         constexpr int buf = decltype(bufc)::value;
@@ -401,14 +404,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
                 float ma, mb;
                 half_wave_pair(mloc, ma, mb);
                 mloc = fmaxf(ma, mb);
-            } else {
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
             }
             // deferred rescale: the running max only moves when these keys exceed it by more than RESCALE_THR (log2
             // units; P stays <= 2^THR), so the O / l rescale and the refresh of the -max block are rare.  The very
-            // first keys always set it.
+            // first keys always set it.  The vote runs over the HALF-row maxima (a query's 32 scores of a block sit in lanes q and
+            // q + 32; any(max(a, b) > thr) == any(a > thr) over the whole wave), so the exchange between the two half-waves -- a
+            // ds_bpermute whose lgkmcnt(0) wait also drains the prefetched fragment reads -- is only paid when the max does move.
             const bool first = (t == 0) && (K0 == 0);
             if (first || __any(mloc > RESCALE_THR)) {
+                if constexpr (!DS) mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
                 const float delta = first ? mloc : fmaxf(mloc, 0.f);
                 const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
                 m_sc[qb] += delta;

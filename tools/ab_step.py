@@ -5,7 +5,7 @@ variants' replays alternated round by round so that clock ramps and box noise hi
 and whether the updated latents are bit-identical to the first variant's.
     python tools/ab_step.py "base" "nt=1" "tattn_nt=1" "nt=1,tattn_nt=3" "GN_MODE=three" [--steps 6] [--rounds 4]
 A variant is a comma-separated list of knob=value (kernels.KNOBS) or NAME=value for an upper-case attribute of imagine360_amd.kernels
-/ imagine360_amd.layers (GN_MODE=three, ROUTE_MIN_TOKENS=32768, ...)."""
+/ imagine360_amd.layers (GN_MODE=three, ROUTE_MIN_TOKENS=32768, ...), or LIB=<path of another build of libim360_kernels.so>."""
 import os
 import statistics
 import sys
@@ -32,7 +32,13 @@ def apply(settings, restore=None):
     """Set the variant's knobs / attributes; returns what to call to get the defaults back."""
     undo = []
     for k, v in settings:
-        if k in kernels.KNOBS:
+        if k == "LIB":
+            # another build of the kernel library (e.g. the previous commit's, kept under tools/experiments/): both are loaded side by
+            # side; the variant's graph is captured with this one's kernels
+            undo.append(("lib", kernels._lib, kernels._LIB_PATH))
+            kernels._lib, kernels._LIB_PATH = None, os.path.abspath(v)
+            kernels.lib()
+        elif k in kernels.KNOBS:
             undo.append(("knob", k))
             kernels.tuning_set(k, int(v))
         else:
@@ -48,7 +54,9 @@ DEFAULT_KNOBS = {}
 
 def revert(undo):
     for u in undo:
-        if u[0] == "knob":
+        if u[0] == "lib":
+            kernels._lib, kernels._LIB_PATH = u[1], u[2]
+        elif u[0] == "knob":
             kernels.tuning_set(u[1], DEFAULT_KNOBS[u[1]])
         else:
             setattr(u[1], u[2], u[3])
