@@ -35,7 +35,7 @@ from imagine360_amd.scheduler import DDIMScheduler  # noqa: E402
 
 # committed measurements this script quotes (one place for the round tag): the PMC traffic summary and the direct CPU step
 HBM_TRAFFIC_JSON = "r06_hbm_traffic.json"          # tools/hbm_traffic.sh on the shipped kernels (non-temporal epilogue stores included)
-CPU_BASELINE_DIRECT = "r05_cpu_baseline_cfg2_direct.json"      # tools/cpu_baseline.py --cfg2-threads 32
+CPU_BASELINE_DIRECT = "r06_cpu_baseline_cfg2_direct.json"      # tools/cpu_baseline.py --cfg2-threads 32
 MFMA_PEAK_TFLOPS = 2500.0       # dense bf16/fp16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0           # HBM3E peak (MI355X_MICROARCH.md; ~6300 GB/s is what a copy kernel reaches)
 WORKLOADS = {
