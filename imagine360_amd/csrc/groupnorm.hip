@@ -312,39 +312,58 @@ __global__ __launch_bounds__(256) void gn_apply_p_kernel(const T* __restrict__ x
             }
             const T* xc = xbase + (c0 + cc) * 8;
             T* yc = yb + coff + (c0 + cc) * 8;
-            auto srcp = [&](int pix) -> uint4 {
-                int sx = pix % Wo - pad;
-                const int sy = pix / Wo;
-                if (sx < 0) sx += W;
-                else if (sx >= W) sx -= W;
+            // (PADDED = false: output pixel == source pixel -- no pix / Wo, pix % Wo per 16-byte piece: the two integer divisions were ~ 60 of the
+            //  ~ 140 vector-issue slots of a piece with SiLU, which put the kernel's VALU ceiling (~ 8 TB/s) right at the HBM roofline)
+            auto srcp = [&](int pix, auto padded_tag) -> uint4 {
+                long off;
+                if constexpr (decltype(padded_tag)::value) {
+                    int sx = pix % Wo - pad;
+                    const int sy = pix / Wo;
+                    if (sx < 0) sx += W;
+                    else if (sx >= W) sx -= W;
+                    off = ((long)sy * W + sx) * Cx;
+                } else {
+                    off = (long)pix * Cx;
+                }
                 if constexpr (NTL) {
-                    const u32x4 r = __builtin_nontemporal_load((const u32x4*)(xc + ((long)sy * W + sx) * Cx));
+                    const u32x4 r = __builtin_nontemporal_load((const u32x4*)(xc + off));
                     return uint4{r.x, r.y, r.z, r.w};
                 } else {
-                    return *(const uint4*)(xc + ((long)sy * W + sx) * Cx);
+                    return *(const uint4*)(xc + off);
                 }
             };
-            auto emit = [&](const uint4& raw, int pix) {
+            // (ACT as a tag: with the run-time `act` hipcc branched around the SiLU of EVERY element -- 32 scalar branches per four pieces, each
+            //  exp / rcp chain alone behind its branch with s_nop wait states; as straight-line code the eight chains of a piece interleave)
+            auto emit = [&](const uint4& raw, int pix, auto act_tag) {
                 float f[8];
                 unpack8<T>(raw, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = f[e] * sc[e] + sh[e];
-                    f[e] = act ? silu_f(v) : v;
+                    f[e] = decltype(act_tag)::value ? silu_f(v) : v;
                 }
                 const uint4 o = pack8<T>(f);
                 if constexpr (NTS) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, (u32x4*)(yc + (long)pix * C));
                 else *(uint4*)(yc + (long)pix * C) = o;
             };
-            int pix = pix0 + pl;
-            for (; pix + (NLD - 1) * lanes < pix1; pix += NLD * lanes) {
-                uint4 r[NLD];
+            auto run = [&](auto padded_tag, auto act_tag) {
+                int pix = pix0 + pl;
+                for (; pix + (NLD - 1) * lanes < pix1; pix += NLD * lanes) {
+                    uint4 r[NLD];
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) r[i] = srcp(pix + i * lanes);
+                    for (int i = 0; i < NLD; ++i) r[i] = srcp(pix + i * lanes, padded_tag);
 #pragma unroll
-                for (int i = 0; i < NLD; ++i) emit(r[i], pix + i * lanes);
+                    for (int i = 0; i < NLD; ++i) emit(r[i], pix + i * lanes, act_tag);
+                }
+                for (; pix < pix1; pix += lanes) emit(srcp(pix, padded_tag), pix, act_tag);
+            };
+            if (pad == 0) {
+                if (act) run(std::false_type{}, std::true_type{});
+                else run(std::false_type{}, std::false_type{});
+            } else {
+                if (act) run(std::true_type{}, std::true_type{});
+                else run(std::true_type{}, std::false_type{});
             }
-            for (; pix < pix1; pix += lanes) emit(srcp(pix), pix);
         }
     }
 }
