@@ -192,43 +192,20 @@ __global__ __launch_bounds__(256) void layernorm_packed_kernel(const T* __restri
     }
 }
 
-// h [rows, 2*I] = (a | gate) -> out [rows, I] = a * gelu(gate).  Where the fused GEGLU GEMM is not used (levels 2 - 3: hipBLASLt does the
-// projection), diffusers/models/activations.py:93-125.  Round 6: one row per wave and trip (no 64-bit i / I8, i % I8 per 16-byte piece), two
-// pieces of the value half and of the gate half in flight per lane, and the SAME transcendental-free Phi as the fused epilogue
-// (gelu_poly_pk: max |error of Phi| 8.9e-6, 50x below fp16 output rounding) instead of erff (~ 40 vector instructions per value, which put
-// this kernel's VALU ceiling below the HBM roofline).
+// h [rows, 2*I] = (a | gate) -> out [rows, I] = a * gelu(gate), exact (erf) GELU
 template <typename T>
-__global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8) {
-    const int lane = threadIdx.x & 63;
-    const long nw = (long)gridDim.x * 4;
-    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+__global__ void geglu_kernel(const T* __restrict__ h, T* __restrict__ out, long rows, int I8) {
+    const long total = rows * I8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / I8;
+        const int c = (int)(i % I8);
         const uint4* hr = (const uint4*)h + r * 2 * I8;
-        uint4* orow = (uint4*)out + r * I8;
-        for (int c0 = lane; c0 < I8; c0 += 128) {
-            const int c1 = c0 + 64;
-            const bool two = c1 < I8;                                  // (the second piece of a ragged last trip re-reads the first)
-            const uint4 ra0 = hr[c0], rg0 = hr[I8 + c0];
-            const uint4 ra1 = hr[two ? c1 : c0], rg1 = hr[I8 + (two ? c1 : c0)];
-            float a[8], g[8];
-            unpack8<T>(ra0, a);
-            unpack8<T>(rg0, g);
+        float a[8], g[8];
+        unpack8<T>(hr[c], a);
+        unpack8<T>(hr[I8 + c], g);
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f32x2 ph = gelu_poly_pk(f32x2{g[e], g[e + 1]});
-                a[e] *= ph.x;
-                a[e + 1] *= ph.y;
-            }
-            orow[c0] = pack8<T>(a);
-            unpack8<T>(ra1, a);
-            unpack8<T>(rg1, g);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f32x2 ph = gelu_poly_pk(f32x2{g[e], g[e + 1]});
-                a[e] *= ph.x;
-                a[e + 1] *= ph.y;
-            }
-            if (two) orow[c1] = pack8<T>(a);
-        }
+        for (int e = 0; e < 8; ++e) a[e] *= 0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f));
+        ((uint4*)out)[i] = pack8<T>(a);
     }
 }
 
@@ -385,8 +362,8 @@ extern "C" __attribute__((visibility("default"))) int im360_geglu(const void* h,
     IM360_CHECK_ARG(h && out, "geglu: null pointer");
     IM360_CHECK_ARG(rows > 0 && I > 0 && (I % 8) == 0, "geglu: I=%ld must be a multiple of 8", (long)I);
     IM360_CHECK_ARG(((uintptr_t)h % 16) == 0 && ((uintptr_t)out % 16) == 0, "geglu: misaligned pointer");
-    const long wgs = (rows + 3) / 4;                              // four rows (one per wave) per workgroup and trip
-    const unsigned blocks = (unsigned)(wgs > 16384 ? 16384 : wgs);
+    const long total = rows * (I / 8);
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     ProfScope prof(PROF_MISC, stream);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == 0)
