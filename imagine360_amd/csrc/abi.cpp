@@ -25,7 +25,7 @@ extern "C" __attribute__((visibility("default"))) const char* im360_last_error(v
 // 2 (round 5): im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer, im360_linear_ln_fwd's table rows include c2
 // (round 4 changed both without bumping the number; callers built against version 1 must not load this library)
 // 3 (round 6): im360_attn_fwd takes the block maps of its packed bias matrices (three trailing arguments)
-extern "C" __attribute__((visibility("default"))) int im360_abi_version(void) { return 4; }
+extern "C" __attribute__((visibility("default"))) int im360_abi_version(void) { return 5; }
 
 // bit 0: built with -DIM360_ABLATE (`make ablate`): the rejected A/B variants and the ablation kernels are in the library
 extern "C" __attribute__((visibility("default"))) int im360_build_flags(void) {
@@ -106,7 +106,7 @@ struct Knobs {
             {im360::KNOB_CONV_BK, "IM360_CONV_BK", 0},       {im360::KNOB_TATTN_SCALAR, "IM360_TATTN_SCALAR", 0},
             {im360::KNOB_CONV_RING, "IM360_CONV_RING", 1},    {im360::KNOB_CONV_HALO, "IM360_CONV_HALO", 0},
             {im360::KNOB_CONV_CM, "IM360_CONV_CM", 1},        {im360::KNOB_LN_PACKED, "IM360_LN_PACKED", 1},
-            {im360::KNOB_RING_GROUPS, "IM360_RING_GROUPS", 0}, {im360::KNOB_ATTN_X, "IM360_ATTN_X", 3}, {im360::KNOB_ATTN_DS, "IM360_ATTN_DS", 0}, {im360::KNOB_ATTN_ONE, "IM360_ATTN_ONE", 1}, {im360::KNOB_ATTN_HG, "IM360_ATTN_HG", 0}, {im360::KNOB_CONV_SMALL, "IM360_CONV_SMALL", 2}, {im360::KNOB_ATTN_W3, "IM360_ATTN_W3", 1}, {im360::KNOB_ATTN_PIPE, "IM360_ATTN_PIPE", -1}, {im360::KNOB_CONV_STAG, "IM360_CONV_STAG", 0}, {im360::KNOB_CONV_PERSIST, "IM360_CONV_PERSIST", 0}, {im360::KNOB_GN_APPLY, "IM360_GN_APPLY", 2}, {im360::KNOB_TATTN_NT, "IM360_TATTN_NT", 0}, {im360::KNOB_NT, "IM360_NT", 1}, {im360::KNOB_G4, "IM360_G4", 0}, {im360::KNOB_GN_WGS, "IM360_GN_WGS", 0},
+            {im360::KNOB_RING_GROUPS, "IM360_RING_GROUPS", 0}, {im360::KNOB_ATTN_X, "IM360_ATTN_X", 3}, {im360::KNOB_ATTN_DS, "IM360_ATTN_DS", 0}, {im360::KNOB_ATTN_ONE, "IM360_ATTN_ONE", 1}, {im360::KNOB_ATTN_HG, "IM360_ATTN_HG", 0}, {im360::KNOB_CONV_SMALL, "IM360_CONV_SMALL", 2}, {im360::KNOB_ATTN_W3, "IM360_ATTN_W3", 1}, {im360::KNOB_ATTN_PIPE, "IM360_ATTN_PIPE", -1}, {im360::KNOB_CONV_STAG, "IM360_CONV_STAG", 0}, {im360::KNOB_CONV_PERSIST, "IM360_CONV_PERSIST", 0}, {im360::KNOB_GN_APPLY, "IM360_GN_APPLY", 2}, {im360::KNOB_TATTN_NT, "IM360_TATTN_NT", 0}, {im360::KNOB_NT, "IM360_NT", 1}, {im360::KNOB_G4, "IM360_G4", 0}, {im360::KNOB_GN_WGS, "IM360_GN_WGS", 0}, {im360::KNOB_CONV_KSPLIT, "IM360_CONV_KSPLIT", 1},
         };
         for (auto& x : v) x.store(0);
         for (auto& i : init) {

@@ -61,6 +61,13 @@ struct ConvParams {
     // non-temporal stores -- tensors of hundreds of MB that should not push the operands out of the L2.  (The same on the attention
     // outputs, which the out-projection reads back at once, cost + 6.7 ms; on the LayerNorm / GEGLU element-wise kernels nothing.)
     int nt_store;
+    // K-split of conv_igemm_kernel's 3 x 3 convolutions (taps innermost; round 6): `ksplit` workgroups share one output tile, each over a
+    // contiguous range of the 64-channel chunks.  Parts 0 .. ksplit - 2 park their fp32 accumulators in ks_ws ([tile][part][160 * 512]
+    // floats, lane-linear) and count themselves into ks_cnt[tile]; the LAST part -- dispatched behind all the others: block ids are part-major --
+    // adds them in part order and runs the epilogue.  For launches whose tile count is not a whole number of rounds of 256 CUs (or below one).
+    int ksplit;
+    float* ks_ws;
+    int* ks_cnt;
 };
 
 // ConvParams with the optional members cleared
@@ -630,6 +637,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
     long bid = blockIdx.x;
+    // K-split (ConvParams::ksplit): block ids are PART-major, so every tile's owner (its last part) is dispatched behind the parts it waits for
+    const int ks_S = (CM && !UP2 && p.ksplit > 1) ? p.ksplit : 1;
+    int ks_part = 0;
+    if (CM && !UP2 && ks_S > 1) {
+        ks_part = (int)(bid / p.nblocks);
+        bid -= (long)ks_part * p.nblocks;
+    }
     {
         const long nb = p.nblocks, q = nb / 8, r = nb % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -674,7 +688,13 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int ksteps_per_tap = p.Cin / BK;
-    const int nsteps = p.ntaps * ksteps_per_tap;
+    int nsteps = p.ntaps * ksteps_per_tap;
+    int ks_c0 = 0;                             // first 64-channel chunk of this part (chunk-major K order: nine taps per chunk)
+    if (CM && !UP2 && ks_S > 1) {
+        ks_c0 = (int)((long)ks_part * ksteps_per_tap / ks_S);
+        const int c1 = (int)((long)(ks_part + 1) * ksteps_per_tap / ks_S);
+        nsteps = (c1 - ks_c0) * p.ntaps;
+    }
 
     // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
     // wrap, upsample, bounds -> source pixel or the zero chunk) is evaluated once per tap, i.e. every Cin / BK
@@ -726,6 +746,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
             aptr[i] = valid ? xg + (((long)(pnv[i] & 0x7fffffffu) * p.Hin + cy) * p.Win + cx) * p.Cin + pd8 : xg;
         }
         tapdelta = -(long)(p.Win + 1) * p.Cin;          // tap 0 = (dy, dx) = (-1, -1)
+        kofs = (long)ks_c0 * BK;
     } else {
         set_tap(0);
     }
@@ -942,6 +963,44 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     static_assert((NT / 64) * 32 * ((EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
+    if constexpr (CM && !UP2) {
+        if (ks_S > 1) {
+            // partial sums of one part: [a][b][r] registers x NT lanes, lane-linear (every store / load instruction one contiguous 2 KB).
+            // Agent-scope relaxed atomics = write-through stores and L2-bypassing loads (the parts of a tile may sit on different XCDs);
+            // "all of this workgroup's stores are acknowledged" (vmcnt(0) + barrier) orders them in front of the counter increment.
+            constexpr int NACC = TN * TM * 16;
+            float* const wst = p.ks_ws + (long)bid * (ks_S - 1) * ((long)NACC * NT);
+            if (ks_part != ks_S - 1) {
+                float* dst = wst + (long)ks_part * ((long)NACC * NT) + tid;
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __hip_atomic_store(dst + ((a * TM + b) * 16 + r) * NT, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(p.ks_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (tid == 0) {
+                while (__hip_atomic_load(p.ks_cnt + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ks_S - 1) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(p.ks_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (self-cleaning: the next launch / graph replay finds zeros)
+            }
+            __syncthreads();
+            for (int q = 0; q < ks_S - 1; ++q) {          // fixed order: own (last) K range + part 0 + part 1 ...
+                const float* src = wst + (long)q * ((long)NACC * NT) + tid;
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[a][b][r] += __hip_atomic_load(src + ((a * TM + b) * 16 + r) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     tile_epilogue<T, NT, TM, TN, EPI, false, UP2, GNS, WN, RESM>(p, acc, lds, m0, n0, wid_s / WN, wid_s % WN, wid_s, lane);
 }
 
@@ -1605,6 +1664,8 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     // 3x3 convolutions without wrap / upsample addressing: taps innermost (see the kernel); the 256 x 320 and 128 x 128 tiles
     constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 3 && TN == 5));
     const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
+    if (!cm || !(WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0)) p.ksplit = 0;       // K-split: the 256 x 320 tile's chunk-major kernels only
+    const unsigned grid_cm = (unsigned)(p.nblocks * (p.ksplit > 1 ? p.ksplit : 1));
     p.dbg = knob(KNOB_CONV_DBG);
 #ifdef IM360_ABLATE
     if constexpr (((WM == 4 && WN == 2) || (WM == 2 && WN == 2 && TM == 3)) && TN == 5 && EPI == 0) {
@@ -1635,15 +1696,15 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
 #endif
         if (p.gn_out) {            // the 256 x 320 tile with GroupNorm statistics from its epilogue (per residual mode of the epilogue)
             if (cm) {
-                if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 1>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
-                else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 2>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+                if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 1>), dim3(grid_cm), dim3(NT), 0, stream, p);
+                else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 2>), dim3(grid_cm), dim3(NT), 0, stream, p);
             } else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }
         if (cm) {
-            if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 1>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
-            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 2>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 1>), dim3(grid_cm), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, false, false, 2>), dim3(grid_cm), dim3(NT), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }
@@ -1802,12 +1863,43 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
     return IM360_OK;
 }
 
+// K-split plan of a convolution launch (ConvParams::ksplit): 1 = none.  Eligible: 3 x 3, taps innermost (no wrap / upsample addressing), the
+// 256 x 320 tile.  T tiles of one K range each take ceil(T / 256) rounds of the chip; S parts per tile take ceil(T S / 256) rounds of 1 / S the
+// length (+ ~ 4 % per extra part for the partial sums' round trip).  Below 512 tiles the alternative is the 128 x 128 tile, which runs at about
+// three quarters of the large tile's rate.  Knob conv_ksplit: 0 = off, 1 = this rule, 2 .. 4 = that many parts wherever eligible.
+static int ksplit_plan(long M, int Cin, int Cout, int ntaps, int up, int wrap, bool gn_stats) {
+    const int kn = knob(KNOB_CONV_KSPLIT);
+    if (kn <= 0 || !knob(KNOB_CONV_BIG) || !knob(KNOB_CONV_CM) || knob(KNOB_CONV_BK) == 32 || knob(KNOB_CONV_RING) >= 5) return 1;
+    if (ntaps != 9 || up || wrap || Cout % 320 != 0 || Cin % 64 != 0 || M > 0x7fffffffL) return 1;
+    const long T = ((M + 255) / 256) * (Cout / 320);
+    const int nch = Cin / 64;
+    if (T < 64 || (gn_stats && T < 512)) return 1;
+    if (kn >= 2 && kn <= 4) return kn <= nch ? kn : 1;
+    // measured inside the step (profiles/r06_conv_ksplit_ab.log): launches below two rounds of the chip -- which otherwise take the 128 x 128 tile --
+    // gain (- 3 ... - 4.7 ms per cfg2 step), the 640-tile launches (2.5 rounds -> five half rounds) LOSE 2 ms to the partial sums' round trip:
+    // the rule is for the former only (knob 5: for every tile count, the A/B; 7 / 8: two / four parts for the former)
+    if (T >= 512 && kn != 5) return 1;
+    if (T < 512 && (kn == 7 || kn == 8)) return (kn == 7 ? 2 : 4) <= nch ? (kn == 7 ? 2 : 4) : 1;
+    double best = T >= 512 ? (double)((T + 255) / 256) : 1.35 * (double)T / 256.0 + 0.15;
+    int bs = 1;
+    for (int S = 2; S <= 4 && S <= nch; ++S) {
+        const double c = (double)((T * S + 255) / 256) / S * (1.0 + 0.04 * (S - 1));
+        if (c < best * 0.93) {          // (at least 7 % on paper)
+            best = c;
+            bs = S;
+        }
+    }
+    return bs;
+}
+
 template <typename T>
-static int launch_conv(const ConvParams& p, hipStream_t stream) {
+static int launch_conv(const ConvParams& p_in, hipStream_t stream) {
+    ConvParams p = p_in;
     const int big_env = knob(KNOB_CONV_BIG);           // tuning overrides
     const int ring_env = knob(KNOB_CONV_RING);
-    // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU)
-    if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && ((p.M + 255) / 256) * (p.Cout / 320) >= 512) {
+    if (!(p.ks_ws && p.ks_cnt && p.ksplit > 1)) p.ksplit = 0;       // (the entry point checked the plan and the buffers)
+    // 256 x 320 tiles once they fill the chip at least twice (one workgroup per CU) -- or in K parts (ksplit_plan)
+    if (big_env && p.Cout % 320 == 0 && p.Cin % 64 == 0 && (((p.M + 255) / 256) * (p.Cout / 320) >= 512 || p.ksplit > 1)) {
         const bool linear = p.ntaps == 1 && p.Hin == 1 && p.Win == 1 && !p.temb;       // EPI 2 has no temb add
 #ifdef IM360_ABLATE
         if (knob(KNOB_CONV_HALO)) {
@@ -1880,12 +1972,13 @@ extern "C" __attribute__((visibility("default"))) int64_t im360_conv_gn_slabs(in
     return hw / 256;
 }
 
-extern "C" __attribute__((visibility("default"))) int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
-                              const void* res, void* y,
-                              int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
-                              int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
-                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
-                              int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial) {
+static int conv_fwd_impl(const void* x, const void* w_packed, const void* bias, const void* temb,
+                         const void* res, void* y,
+                         int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                         int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                         int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
+                         int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial,
+                         void* ks_ws, int64_t ks_ws_bytes, void* ks_cnt, int64_t ks_cnt_n) {
     using namespace im360;
     IM360_CHECK_ARG(x && w_packed && y, "conv_fwd: null pointer");
     IM360_CHECK_ARG(!gn_partial || (im360_conv_gn_slabs(N, Hout, Wout, Cin, Cout, ntaps) > 0 && !up), "conv_fwd: this launch cannot produce GroupNorm statistics (im360_conv_gn_slabs == 0)");
@@ -1907,6 +2000,18 @@ extern "C" __attribute__((visibility("default"))) int im360_conv_fwd(const void*
     p.imgs_per_temb = temb ? (int)imgs_per_temb : 1;
     p.M = N * Hout * Wout;
     p.gn_out = (float*)gn_partial;
+    if (ks_ws || ks_cnt) {
+        const int S = ksplit_plan(p.M, p.Cin, p.Cout, p.ntaps, p.up, p.wrap, gn_partial != nullptr);
+        const int64_t tiles = Cout % 320 == 0 ? ((p.M + 255) / 256) * (Cout / 320) : 0;
+        IM360_CHECK_ARG(S > 1, "conv_fwd_ksplit: im360_conv_ksplit_plan gives no K-split for this launch");
+        IM360_CHECK_ARG(ks_ws && ks_cnt && ((uintptr_t)ks_ws % 16) == 0 && ((uintptr_t)ks_cnt % 4) == 0 && ks_cnt_n >= tiles &&
+                        ks_ws_bytes >= tiles * (S - 1) * (int64_t)(160 * 512 * 4),
+                        "conv_fwd_ksplit: %ld tiles x %d parts need %ld workspace bytes and %ld zeroed counters", (long)tiles, S,
+                        (long)(tiles * (S - 1) * (int64_t)(160 * 512 * 4)), (long)tiles);
+        p.ksplit = S;
+        p.ks_ws = (float*)ks_ws;
+        p.ks_cnt = (int*)ks_cnt;
+    }
     hipStream_t s = (hipStream_t)stream;
     // token-major linears routed through the kernel (1x1 taps on a [M, 1, 1, K] view) are accounted separately
     ProfScope prof(ntaps == 1 && Hin == 1 && Win == 1 ? PROF_GEMM : PROF_CONV, stream);
@@ -1914,6 +2019,40 @@ extern "C" __attribute__((visibility("default"))) int im360_conv_fwd(const void*
     if (dtype == 1) return launch_conv<_Float16>(p, s);
     im360_set_error("conv_fwd: dtype %d unsupported", dtype);
     return IM360_ERR_UNSUPPORTED;
+}
+
+extern "C" __attribute__((visibility("default"))) int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const void* temb,
+                              const void* res, void* y,
+                              int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                              int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
+                              int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial) {
+    return conv_fwd_impl(x, w_packed, bias, temb, res, y, N, Hin, Win, Cin, Hout, Wout, Cout, ntaps, stride, up, wrap, x_off, y_off, imgs_per_temb, dtype, stream,
+                         gn_partial, nullptr, 0, nullptr, 0);
+}
+
+// K parts per output tile im360_conv_fwd_ksplit would run this launch in (1 = none: call im360_conv_fwd), knob conv_ksplit included.
+extern "C" __attribute__((visibility("default"))) int64_t im360_conv_ksplit_plan(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps,
+                                                                                 int64_t up, int64_t wrap, int64_t gn_stats) {
+    using namespace im360;
+    if (N <= 0 || Hout <= 0 || Wout <= 0 || Cin <= 0 || Cout <= 0 || Cin > 0x7fffffffL || Cout > 0x7fffffffL) return 1;
+    return ksplit_plan(N * Hout * Wout, (int)Cin, (int)Cout, (int)ntaps, up ? 1 : 0, wrap ? 1 : 0, gn_stats != 0);
+}
+
+// im360_conv_fwd with every output tile's K range split over im360_conv_ksplit_plan(...) workgroups (ConvParams::ksplit).  ks_ws: tiles x (parts - 1)
+// x 327 680 bytes of scratch (tiles = ceil(N Hout Wout / 256) x Cout / 320); ks_cnt: `tiles` int32 counters, ZERO on entry, zero again on return.
+// Deterministic (fixed summation order), not bit-identical to the unsplit launch (another order of the fp32 partial sums).
+extern "C" __attribute__((visibility("default"))) int im360_conv_fwd_ksplit(const void* x, const void* w_packed, const void* bias, const void* temb,
+                              const void* res, void* y,
+                              int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                              int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                              int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
+                              int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial,
+                              void* ks_ws, int64_t ks_ws_bytes, void* ks_cnt, int64_t ks_cnt_n) {
+    using namespace im360;
+    IM360_CHECK_ARG(ks_ws && ks_cnt, "conv_fwd_ksplit: null workspace");
+    return conv_fwd_impl(x, w_packed, bias, temb, res, y, N, Hin, Win, Cin, Hout, Wout, Cout, ntaps, stride, up, wrap, x_off, y_off, imgs_per_temb, dtype, stream,
+                         gn_partial, ks_ws, ks_ws_bytes, ks_cnt, ks_cnt_n);
 }
 
 // nearest-x2 upsample + conv3x3 (pad 1) as four 2 x 2 convolutions of the low-resolution input, one per output parity:

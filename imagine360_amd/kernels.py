@@ -36,6 +36,8 @@ _SIGNATURES = {
     "im360_linear_geglu_ln": (_INT, [_PTR] * 5 + [_I64, _F32, _PTR] + [_I64] * 3 + [_INT, _PTR]),
     "im360_conv_fwd": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR, _PTR]),
     "im360_conv_gn_slabs": (_I64, [_I64] * 6),
+    "im360_conv_ksplit_plan": (_I64, [_I64] * 9),
+    "im360_conv_fwd_ksplit": (_INT, [_PTR] * 6 + [_I64] * 14 + [_INT, _PTR, _PTR] + [_PTR, _I64, _PTR, _I64]),
     "im360_groupnorm_partial": (_INT, [_PTR] * 2 + [_I64] * 4 + [_INT, _PTR]),
     "im360_groupnorm_finalize": (_INT, [_PTR, _I64, _I64, _PTR, _I64, _I64] + [_PTR] * 4 + [_I64] * 3 + [_F32, _INT, _PTR]),
     "im360_groupnorm_partial_pad": (_INT, [_PTR] * 2 + [_I64] * 5 + [_INT, _PTR]),
@@ -57,7 +59,7 @@ _SIGNATURES = {
     "im360_prof_collect": (_INT, [_INT, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
 }
 
-ABI_VERSION = 4          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
+ABI_VERSION = 5          # include/im360_kernels.h: what im360_abi_version() of a matching library returns
 
 PROF_KINDS = {"attn": 0, "temporal": 1, "conv": 2, "gn_stats": 3, "gn_apply": 4, "misc": 5, "gemm": 6, "attn_warp": 7, "attn_x2": 8}
 
@@ -533,10 +535,21 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
         slabs = lib().im360_conv_gn_slabs(N, hout, wout, Cin, cout, taps)
         if slabs > 0:
             gn = torch.empty((N * slabs * 2 * cout,), dtype=torch.float32, device=x.device)
-    rc = lib().im360_conv_fwd(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
-                              N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
-                              imgs_per_temb, _dt(x), _stream(), _p(gn))
-    _check(rc, "im360_conv_fwd")
+    # K-split (knob conv_ksplit): launches whose tile count is not a whole number of rounds of the chip run every tile in `parts` workgroups
+    parts = lib().im360_conv_ksplit_plan(N, hout, wout, Cin, cout, taps, int(up), int(wrap), int(gn is not None)) if taps == 9 else 1
+    if parts > 1:
+        tiles = -(-(N * hout * wout) // 256) * (cout // 320)
+        ws = torch.empty((tiles * (parts - 1) * 160 * 512,), dtype=torch.float32, device=x.device)
+        cnt = torch.zeros((tiles,), dtype=torch.int32, device=x.device)
+        rc = lib().im360_conv_fwd_ksplit(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
+                                         N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
+                                         imgs_per_temb, _dt(x), _stream(), _p(gn), _p(ws), ws.numel() * 4, _p(cnt), tiles)
+        _check(rc, "im360_conv_fwd_ksplit")
+    else:
+        rc = lib().im360_conv_fwd(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
+                                  N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,
+                                  imgs_per_temb, _dt(x), _stream(), _p(gn))
+        _check(rc, "im360_conv_fwd")
     if gn is not None:
         _tag_gn(y, gn, slabs)
     if STATS is not None or SHAPES is not None:
@@ -829,7 +842,7 @@ def cfg_ddim_update(uncond, cond, sample, guidance, cx, cv, coef_dev=None):
 
 # ------------------------------------------------------------------------------------------ tuning knobs
 KNOBS = {"attn_qb": 0, "conv_big": 1, "conv_bk": 2, "tattn_scalar": 3, "conv_ring": 4, "attn_hl": 5, "conv_dbg": 6, "conv_halo": 7, "conv_cm": 8, "ln_packed": 9,
-         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20, "gn_apply": 21, "tattn_nt": 22, "nt": 23, "g4": 24, "gn_wgs": 25}
+         "ring_groups": 10, "attn_x": 11, "attn_ds": 12, "attn_one": 13, "attn_dbg": 14, "attn_hg": 15, "conv_small": 16, "attn_w3": 17, "attn_pipe": 18, "conv_stag": 19, "conv_persist": 20, "gn_apply": 21, "tattn_nt": 22, "nt": 23, "g4": 24, "gn_wgs": 25, "conv_ksplit": 26}
 
 
 ATTN_PIPE_DEFAULT = -1         # the library's default for the attn_pipe knob (abi.cpp)

@@ -16,7 +16,8 @@
 extern "C" {
 #endif
 
-/* 4 since round 6 (3: packed-bias block maps of im360_attn_fwd; 4: im360_groupnorm_partial_pad / im360_groupnorm_apply_partials added).
+/* 5 since round 6 (3: packed-bias block maps of im360_attn_fwd; 4: im360_groupnorm_partial_pad / im360_groupnorm_apply_partials added;
+ * 5: im360_conv_ksplit_plan / im360_conv_fwd_ksplit added).
  * 2 since round 5: im360_conv_fwd / im360_linear_fwd take a trailing gn_partial pointer and the table rows of
  * im360_linear_ln_fwd include c2 (both introduced in round 4 under version 1).  imagine360_amd/kernels.py refuses a mismatch. */
 int im360_abi_version(void);
@@ -169,6 +170,24 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
  * (animatediff/models/resnet.py:221-243 is norm -> SiLU -> conv twice).  Only launches for which im360_conv_gn_slabs
  * returns S > 0 (slabs per image) can do it. */
 int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps);
+
+/* K-split of a 3x3 convolution launch (ABI version 5): every 256 x 320 output tile is computed by `parts` workgroups, each over a
+ * contiguous range of the 64-channel chunks of K; parts 0 .. parts - 2 park their fp32 accumulators in ks_ws, the last one (dispatched
+ * behind them) adds them in part order and runs the usual epilogue.  For launches whose tile count is not a whole number of rounds
+ * of the chip's 256 CUs (perspective level 2 of cfg2: 640 tiles = 2.5 rounds) or below one round (level 3: 160 tiles).
+ * im360_conv_ksplit_plan: parts this launch would run in (1 = none: call im360_conv_fwd; knob conv_ksplit 0 = never).
+ * im360_conv_fwd_ksplit: im360_conv_fwd + the scratch: ks_ws >= tiles x (parts - 1) x 327 680 bytes (tiles = ceil(N Hout Wout / 256)
+ * x Cout / 320), ks_cnt = `tiles` int32 counters, ZERO on entry and zero again on return.  Deterministic; not bit-identical to the
+ * unsplit launch (another order of the fp32 partial sums).  Same call sites as im360_conv_fwd (animatediff/models/resnet.py:19-27). */
+int64_t im360_conv_ksplit_plan(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps,
+                               int64_t up, int64_t wrap, int64_t gn_stats);
+int im360_conv_fwd_ksplit(const void* x, const void* w_packed, const void* bias, const void* temb,
+                          const void* res, void* y,
+                          int64_t N, int64_t Hin, int64_t Win, int64_t Cin,
+                          int64_t Hout, int64_t Wout, int64_t Cout, int64_t ntaps,
+                          int64_t stride, int64_t up, int64_t wrap, int64_t x_off, int64_t y_off,
+                          int64_t imgs_per_temb, int dtype, void* stream, void* gn_partial,
+                          void* ks_ws, int64_t ks_ws_bytes, void* ks_cnt, int64_t ks_cnt_n);
 
 /* 1x1 convolution of the channel concatenation [xa | xb] without materialising it: the K loop reads channels [0, C1)
  * from xa and [C1, C1 + C2) from xb (C1, C2 multiples of 64); w_packed [CoutPad][1][C1 + C2]; + bias + res.

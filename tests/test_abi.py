@@ -40,13 +40,13 @@ def test_binding_rejects_a_library_of_another_abi_version(monkeypatch):
     monkeypatch.setattr(kernels, "ABI_VERSION", 1)
     with pytest.raises(RuntimeError, match="C-ABI version"):
         kernels.lib()
-    monkeypatch.setattr(kernels, "ABI_VERSION", 4)
-    assert kernels.lib().im360_abi_version() == 4
+    monkeypatch.setattr(kernels, "ABI_VERSION", 5)
+    assert kernels.lib().im360_abi_version() == 5
 
 
 def test_python_binding_covers_header():
     assert set(declared_symbols()) == set(kernels.exported_symbols())
-    assert kernels.lib().im360_abi_version() == kernels.ABI_VERSION == 4
+    assert kernels.lib().im360_abi_version() == kernels.ABI_VERSION == 5
     assert kernels.lib().im360_last_error() is not None
 
 

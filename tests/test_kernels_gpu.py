@@ -42,7 +42,7 @@ def q16(t, dt):
 
 
 def test_library_loads():
-    assert K.lib().im360_abi_version() == K.ABI_VERSION == 4
+    assert K.lib().im360_abi_version() == K.ABI_VERSION == 5
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -682,6 +682,48 @@ def test_conv3x3_chunk_major_k_order(dt, N, H, W, Cin, Cout, kw):
         K.tuning_set("conv_cm", 1)
     assert rel(outs[0], ref) < TOL[dt] and rel(outs[1], ref) < TOL[dt]
     assert rel(outs[0], outs[1].float().cpu()) < TOL[dt] / 4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,Cin,Cout,kw", [(160, 8, 8, 256, 1280, dict()),                  # 160 tiles (level-3 like): below one round of the chip
+                                               (100, 16, 16, 192, 640, dict()),                 # 200 tiles, three chunks: parts of 1 + 1 + 1 / 1 + 2 chunks
+                                               (77, 16, 16, 128, 320, dict()),                  # ragged last pixel tile
+                                               (320, 16, 16, 128, 640, dict(stride=2))])        # stride 2
+def test_conv3x3_k_split_equals_the_unsplit_launch(dt, N, H, W, Cin, Cout, kw):
+    """Knob conv_ksplit (round 6): every 256 x 320 tile of a 3 x 3 convolution computed by 2 - 4 workgroups over contiguous ranges of the
+    64-channel chunks, partial sums through a scratch buffer in a fixed order -- against the unsplit launch (fp32 summation order only), the
+    fp32 reference, itself (deterministic), with bias, time embedding and residual; the planner's own choice (knob 1) as well."""
+    g = torch.Generator().manual_seed(97)
+    x = q16(torch.randn(N, H, W, Cin, generator=g), dt)
+    w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
+    b = q16(torch.randn(Cout, generator=g) * 0.1, dt)
+    stride = kw.get("stride", 1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1, stride=stride).permute(0, 2, 3, 1)
+    temb = q16(torch.randn(N, Cout, generator=g), dt)
+    res = q16(torch.randn(ref.shape, generator=g), dt)
+    ref = ref + temb[:, None, None, :] + res
+    wp = K.pack_conv_weight(w.to(dt).cuda())
+    args = dict(bias=b.to(dt).cuda(), temb=temb.to(dt).cuda(), imgs_per_temb=1, res=res.to(dt).cuda(), **kw)
+    xd = x.to(dt).cuda()
+    lib = K.lib()
+    ho, wo = H // stride, W // stride
+    try:
+        K.tuning_set("conv_ksplit", 0)
+        assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 0, 0) == 1
+        base = K.conv2d(xd, wp, Cout, **args)
+        assert rel(base, ref) < TOL[dt]
+        for knob in (2, 3, 4, 1, 5):
+            K.tuning_set("conv_ksplit", knob)
+            parts = lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 0, 0)
+            if 2 <= knob <= 4:
+                assert parts == (knob if knob <= Cin // 64 else 1), (knob, parts)
+            assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 1, 0) == 1        # wrap addressing: tap-major kernel, no split
+            out = K.conv2d(xd, wp, Cout, **args)
+            assert rel(out, ref) < TOL[dt] and blockrel(out, ref, 32) < 2 * TOL[dt], (knob, parts)
+            assert rel(out, base.float().cpu()) < TOL[dt] / 8, (knob, parts)
+            assert torch.equal(out, K.conv2d(xd, wp, Cout, **args)), (knob, parts)           # fixed order; the counters came back to zero
+    finally:
+        K.tuning_set("conv_ksplit", 1)          # the library's default: the planner's rule
 
 
 @pytest.mark.parametrize("dt", DTYPES)
