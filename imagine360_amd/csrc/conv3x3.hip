@@ -638,9 +638,11 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
     long bid = blockIdx.x;
     // K-split (ConvParams::ksplit): block ids are PART-major, so every tile's owner (its last part) is dispatched behind the parts it waits for
-    const int ks_S = (CM && !UP2 && p.ksplit > 1) ? p.ksplit : 1;
+    // (compiled into the 256 x 320 tile's 3 x 3 kernels: chunk-major and -- the panorama's wrap-addressed convolutions -- tap-major K order)
+    constexpr bool KSOK = WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0 && !UP2 && !ABL && !STAG;
+    const int ks_S = (KSOK && p.ksplit > 1) ? p.ksplit : 1;
     int ks_part = 0;
-    if (CM && !UP2 && ks_S > 1) {
+    if (KSOK && ks_S > 1) {
         ks_part = (int)(bid / p.nblocks);
         bid -= (long)ks_part * p.nblocks;
     }
@@ -689,11 +691,17 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     const int ksteps_per_tap = p.Cin / BK;
     int nsteps = p.ntaps * ksteps_per_tap;
-    int ks_c0 = 0;                             // first 64-channel chunk of this part (chunk-major K order: nine taps per chunk)
-    if (CM && !UP2 && ks_S > 1) {
-        ks_c0 = (int)((long)ks_part * ksteps_per_tap / ks_S);
-        const int c1 = (int)((long)(ks_part + 1) * ksteps_per_tap / ks_S);
-        nsteps = (c1 - ks_c0) * p.ntaps;
+    int ks_c0 = 0;                             // chunk-major K order (nine taps per chunk): first 64-channel chunk of this part
+    int ks_s0 = 0;                             // tap-major K order (Cin / 64 steps per tap): first step of this part
+    if (KSOK && ks_S > 1) {
+        if constexpr (CM) {
+            ks_c0 = (int)((long)ks_part * ksteps_per_tap / ks_S);
+            const int c1 = (int)((long)(ks_part + 1) * ksteps_per_tap / ks_S);
+            nsteps = (c1 - ks_c0) * p.ntaps;
+        } else {
+            ks_s0 = (int)((long)ks_part * nsteps / ks_S);
+            nsteps = (int)((long)(ks_part + 1) * nsteps / ks_S) - ks_s0;
+        }
     }
 
     // Producer state of the LDS-DMA stream.  Per K-step only pointer bumps remain: the tap geometry (shift,
@@ -748,7 +756,16 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
         tapdelta = -(long)(p.Win + 1) * p.Cin;          // tap 0 = (dy, dx) = (-1, -1)
         kofs = (long)ks_c0 * BK;
     } else {
-        set_tap(0);
+        // (a K part of the tap-major order starts inside tap ks_s0 / steps-per-tap: that tap's pixel pointers, advanced by the channel chunks
+        //  in front of it; the packed weights [cout][tap][cin] are contiguous across taps: one offset)
+        tap_p = ks_s0 / ksteps_per_tap;
+        kk_p = ks_s0 % ksteps_per_tap;
+        set_tap(tap_p);
+        if (ks_s0) {
+#pragma unroll
+            for (int i = 0; i < LDA; ++i) aptr[i] += ((amask >> i) & 1u) ? kk_p * BK : 0;
+            bptr += (long)ks_s0 * BK;
+        }
     }
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);          // wave-uniform: LDS-DMA destinations stay in SGPRs
 
@@ -963,7 +980,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     static_assert((NT / 64) * 32 * ((EPI == 1 || EPI == 4) ? (TN / 2) * 64 : TN * 64) <= 2 * STAGE, "epilogue staging exceeds the K-loop LDS");
     __syncthreads();                              // every wave is done reading the operand tiles
-    if constexpr (CM && !UP2) {
+    if constexpr (KSOK) {
         if (ks_S > 1) {
             // partial sums of one part: [a][b][r] registers x NT lanes, lane-linear (every store / load instruction one contiguous 2 KB).
             // Agent-scope relaxed atomics = write-through stores and L2-bypassing loads (the parts of a tile may sit on different XCDs);
@@ -1664,7 +1681,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
     // 3x3 convolutions without wrap / upsample addressing: taps innermost (see the kernel); the 256 x 320 and 128 x 128 tiles
     constexpr bool has_cm = EPI == 0 && ((WM == 4 && WN == 2 && TN == 5) || (WM == 2 && WN == 2 && TN == 2) || (WM == 2 && WN == 2 && TM == 3 && TN == 5));
     const bool cm = has_cm && knob(KNOB_CONV_CM) && p.ntaps == 9 && !p.wrap && !p.up && p.Cin % 64 == 0 && bk_env != 32;
-    if (!cm || !(WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0)) p.ksplit = 0;       // K-split: the 256 x 320 tile's chunk-major kernels only
+    if (!(WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0) || p.ntaps != 9 || p.up || p.Cin % 64 != 0 || bk_env == 32) p.ksplit = 0;       // K-split: the 256 x 320 tile's 3 x 3 kernels only
     const unsigned grid_cm = (unsigned)(p.nblocks * (p.ksplit > 1 ? p.ksplit : 1));
     p.dbg = knob(KNOB_CONV_DBG);
 #ifdef IM360_ABLATE
@@ -1698,7 +1715,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
             if (cm) {
                 if (p.res) hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 1>), dim3(grid_cm), dim3(NT), 0, stream, p);
                 else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true, false, false, true, false, 2>), dim3(grid_cm), dim3(NT), 0, stream, p);
-            } else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+            } else hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, false, false, false, true>), dim3(grid_cm), dim3(NT), 0, stream, p);
             IM360_CHECK_LAUNCH();
             return IM360_OK;
         }
@@ -1717,7 +1734,7 @@ static int launch_conv_t(ConvParams p, hipStream_t stream) {
         if constexpr (has_cm)
             hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI, true>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     } else if ((p.Cin % 64 == 0 && bk_env != 32 && !(WM == 2 && TN >= 4 && TM == 2) && !(WM == 4 && WN == 1 && knob(KNOB_CONV_SMALL) == 0)) || !has_bk32) {      // (the 128 x 320 / 128 x 256 tiles exist for two workgroups per CU: 32-channel stages)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 64, WM, WN, TM, TN, EPI>), dim3(grid_cm), dim3(NT), 0, stream, p);
     } else if constexpr (has_bk32) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 32, WM, WN, TM, TN, EPI>), dim3((unsigned)p.nblocks), dim3(NT), 0, stream, p);
     }
@@ -1870,7 +1887,9 @@ static int launch_ring_t(ConvParams p, hipStream_t stream, int variant) {
 static int ksplit_plan(long M, int Cin, int Cout, int ntaps, int up, int wrap, bool gn_stats) {
     const int kn = knob(KNOB_CONV_KSPLIT);
     if (kn <= 0 || !knob(KNOB_CONV_BIG) || !knob(KNOB_CONV_CM) || knob(KNOB_CONV_BK) == 32 || knob(KNOB_CONV_RING) >= 5) return 1;
-    if (ntaps != 9 || up || wrap || Cout % 320 != 0 || Cin % 64 != 0 || M > 0x7fffffffL) return 1;
+    if (ntaps != 9 || up || Cout % 320 != 0 || Cin % 64 != 0 || M > 0x7fffffffL) return 1;
+    if (wrap && kn == 1) return 1;              // (the panorama's wrap-addressed, tap-major launches split correctly but gain nothing inside the step -- they run beside the
+                                                //  perspective branch: 290.2 vs 289.9 ms, profiles/r06_conv_ksplit_ab.log -- so the rule leaves them alone; knob 9 = the rule for them too)
     const long T = ((M + 255) / 256) * (Cout / 320);
     const int nch = Cin / 64;
     if (T < 64 || (gn_stats && T < 512)) return 1;
@@ -1878,7 +1897,8 @@ static int ksplit_plan(long M, int Cin, int Cout, int ntaps, int up, int wrap, b
     // measured inside the step (profiles/r06_conv_ksplit_ab.log): launches below two rounds of the chip -- which otherwise take the 128 x 128 tile --
     // gain (- 3 ... - 4.7 ms per cfg2 step), the 640-tile launches (2.5 rounds -> five half rounds) LOSE 2 ms to the partial sums' round trip:
     // the rule is for the former only (knob 5: for every tile count, the A/B; 7 / 8: two / four parts for the former)
-    if (T >= 512 && kn != 5) return 1;
+    if (kn == 9) { if (T >= 512) return 1; }
+    else if (T >= 512 && kn != 5) return 1;
     if (T < 512 && (kn == 7 || kn == 8)) return (kn == 7 ? 2 : 4) <= nch ? (kn == 7 ? 2 : 4) : 1;
     double best = T >= 512 ? (double)((T + 255) / 256) : 1.35 * (double)T / 256.0 + 0.15;
     int bs = 1;

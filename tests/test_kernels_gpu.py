@@ -688,7 +688,9 @@ def test_conv3x3_chunk_major_k_order(dt, N, H, W, Cin, Cout, kw):
 @pytest.mark.parametrize("N,H,W,Cin,Cout,kw", [(160, 8, 8, 256, 1280, dict()),                  # 160 tiles (level-3 like): below one round of the chip
                                                (100, 16, 16, 192, 640, dict()),                 # 200 tiles, three chunks: parts of 1 + 1 + 1 / 1 + 2 chunks
                                                (77, 16, 16, 128, 320, dict()),                  # ragged last pixel tile
-                                               (320, 16, 16, 128, 640, dict(stride=2))])        # stride 2
+                                               (320, 16, 16, 128, 640, dict(stride=2)),         # stride 2
+                                               (32, 16, 36, 256, 1280, dict(wrap=True)),        # panorama level-2 like: circular wrap = tap-major K order, parts start inside a tap
+                                               (32, 8, 20, 192, 1280, dict(wrap=True))])        # level-3 like, 27 steps over 2 - 3 parts
 def test_conv3x3_k_split_equals_the_unsplit_launch(dt, N, H, W, Cin, Cout, kw):
     """Knob conv_ksplit (round 6): every 256 x 320 tile of a 3 x 3 convolution computed by 2 - 4 workgroups over contiguous ranges of the
     64-channel chunks, partial sums through a scratch buffer in a fixed order -- against the unsplit launch (fp32 summation order only), the
@@ -697,8 +699,8 @@ def test_conv3x3_k_split_equals_the_unsplit_launch(dt, N, H, W, Cin, Cout, kw):
     x = q16(torch.randn(N, H, W, Cin, generator=g), dt)
     w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, dt)
     b = q16(torch.randn(Cout, generator=g) * 0.1, dt)
-    stride = kw.get("stride", 1)
-    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1, stride=stride).permute(0, 2, 3, 1)
+    stride, wrap = kw.get("stride", 1), kw.get("wrap", False)
+    ref = _conv_ref(x, w, b, wrap_pad=1, unpad=1) if wrap else F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1, stride=stride).permute(0, 2, 3, 1)
     temb = q16(torch.randn(N, Cout, generator=g), dt)
     res = q16(torch.randn(ref.shape, generator=g), dt)
     ref = ref + temb[:, None, None, :] + res
@@ -709,15 +711,15 @@ def test_conv3x3_k_split_equals_the_unsplit_launch(dt, N, H, W, Cin, Cout, kw):
     ho, wo = H // stride, W // stride
     try:
         K.tuning_set("conv_ksplit", 0)
-        assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 0, 0) == 1
+        assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, int(wrap), 0) == 1
         base = K.conv2d(xd, wp, Cout, **args)
         assert rel(base, ref) < TOL[dt]
-        for knob in (2, 3, 4, 1, 5):
+        for knob in (2, 3, 4, 1, 5, 9):
             K.tuning_set("conv_ksplit", knob)
-            parts = lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 0, 0)
+            parts = lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, int(wrap), 0)
             if 2 <= knob <= 4:
                 assert parts == (knob if knob <= Cin // 64 else 1), (knob, parts)
-            assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 0, 1, 0) == 1        # wrap addressing: tap-major kernel, no split
+            assert lib.im360_conv_ksplit_plan(N, ho, wo, Cin, Cout, 9, 1, int(wrap), 0) == 1        # upsample addressing: no split
             out = K.conv2d(xd, wp, Cout, **args)
             assert rel(out, ref) < TOL[dt] and blockrel(out, ref, 32) < 2 * TOL[dt], (knob, parts)
             assert rel(out, base.float().cpu()) < TOL[dt] / 8, (knob, parts)
