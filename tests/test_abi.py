@@ -180,3 +180,19 @@ def test_default_path_kernels_do_not_spill():
         assert not bad, bad
     finally:
         shutil.rmtree(tmp)
+
+
+def test_conv_k_split_planner_rule():
+    """im360_conv_ksplit_plan is host code: the shipped rule (knob conv_ksplit = 1) splits 3 x 3 launches BELOW 512 large tiles only (measured: the
+    level-3 convolutions of cfg2 gain, the 640-tile level-2 ones lose -- profiles/r06_conv_ksplit_ab.log), never the upsample / wrap-addressed
+    ones, and never launches that write GroupNorm statistics from fewer than 512 tiles."""
+    lib = kernels.lib()
+    plan = lambda N, H, W, Cin, Cout, taps=9, up=0, wrap=0, gn=0: lib.im360_conv_ksplit_plan(N, H, W, Cin, Cout, taps, up, wrap, gn)
+    assert plan(640, 4, 4, 1280, 1280) == 3            # cfg2 perspective level 3: 160 tiles -> three parts (480 workgroups)
+    assert plan(640, 8, 8, 1280, 1280) == 1            # level 2: 640 tiles = 2.5 rounds: unsplit
+    assert plan(640, 16, 16, 640, 640) == 1            # level 1: 1280 tiles
+    assert plan(32, 8, 16, 1280, 1280) in (2, 3, 4)    # panorama level 3 (pre-padded window, no wrap flag): 64 tiles
+    assert plan(32, 8, 20, 1280, 1280, wrap=1) == 1    # wrap addressing: left alone by the rule
+    assert plan(640, 4, 4, 1280, 1280, up=1) == 1 and plan(640, 4, 4, 1280, 1280, taps=1) == 1
+    assert plan(640, 4, 4, 1280, 1280, gn=1) == 1      # statistics epilogue needs >= 512 tiles
+    assert plan(640, 4, 4, 1280, 1000) == 1 and plan(640, 4, 4, 96, 1280) == 1      # not the 256 x 320 tile / not whole 64-channel chunks
