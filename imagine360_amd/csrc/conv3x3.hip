@@ -62,9 +62,9 @@ struct ConvParams {
     // outputs, which the out-projection reads back at once, cost + 6.7 ms; on the LayerNorm / GEGLU element-wise kernels nothing.)
     int nt_store;
     // K-split of conv_igemm_kernel's 3 x 3 convolutions (taps innermost; round 6): `ksplit` workgroups share one output tile, each over a
-    // contiguous range of the 64-channel chunks.  Every part parks its fp32 accumulators in ks_ws ([tile][part][160 * 512] floats, lane-linear)
-    // and counts itself into ks_cnt[tile]; the part that arrives last adds them in part order and runs the epilogue (nobody waits).  For launches
-    // of fewer tiles than fill the chip twice (they used to take the 128 x 128 tile).
+    // contiguous range of the 64-channel chunks.  Parts 0 .. ksplit - 2 park their fp32 accumulators in ks_ws ([tile][part][160 * 512]
+    // floats, lane-linear) and count themselves into ks_cnt[tile]; the LAST part -- dispatched behind all the others: block ids are part-major --
+    // adds them in part order and runs the epilogue.  For launches whose tile count is not a whole number of rounds of 256 CUs (or below one).
     int ksplit;
     float* ks_ws;
     int* ks_cnt;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 
     // XCD-aware tile order: consecutive logical tiles (same pixel tile, neighbouring cout tiles) share an L2
     long bid = blockIdx.x;
-    // K-split (ConvParams::ksplit): block ids are part-major (all first parts, then all second parts, ...)
+    // K-split (ConvParams::ksplit): block ids are PART-major, so every tile's owner (its last part) is dispatched behind the parts it waits for
     // (compiled into the 256 x 320 tile's 3 x 3 kernels: chunk-major and -- the panorama's wrap-addressed convolutions -- tap-major K order)
     constexpr bool KSOK = WM == 4 && WN == 2 && TM == 2 && TN == 5 && EPI == 0 && !UP2 && !ABL && !STAG;
     const int ks_S = (KSOK && p.ksplit > 1) ? p.ksplit : 1;
@@ -982,15 +982,12 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
     __syncthreads();                              // every wave is done reading the operand tiles
     if constexpr (KSOK) {
         if (ks_S > 1) {
-            // EVERY part parks its fp32 accumulators ([a][b][r] registers x NT lanes, lane-linear: every store / load instruction one contiguous
-            // 2 KB) and counts itself in; the part that arrives LAST -- whichever it is: nobody waits for anybody, so no assumption about the
-            // order in which workgroups are dispatched and no way to deadlock two concurrent launches -- adds all parts in part order 0 .. S - 1
-            // (a fixed order: deterministic bits) and runs the epilogue.  Agent-scope relaxed atomics = write-through stores and L2-bypassing
-            // loads (the parts of a tile may sit on different XCDs); "all of this workgroup's stores are acknowledged" (vmcnt(0) + barrier)
-            // orders them in front of its increment, and the increments are totally ordered.
+            // partial sums of one part: [a][b][r] registers x NT lanes, lane-linear (every store / load instruction one contiguous 2 KB).
+            // Agent-scope relaxed atomics = write-through stores and L2-bypassing loads (the parts of a tile may sit on different XCDs);
+            // "all of this workgroup's stores are acknowledged" (vmcnt(0) + barrier) orders them in front of the counter increment.
             constexpr int NACC = TN * TM * 16;
-            float* const wst = p.ks_ws + (long)bid * ks_S * ((long)NACC * NT);
-            {
+            float* const wst = p.ks_ws + (long)bid * (ks_S - 1) * ((long)NACC * NT);
+            if (ks_part != ks_S - 1) {
                 float* dst = wst + (long)ks_part * ((long)NACC * NT) + tid;
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
@@ -999,30 +996,25 @@ __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(TM
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             __hip_atomic_store(dst + ((a * TM + b) * 16 + r) * NT, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(p.ks_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int* const flag = (int*)lds;                 // (the operand tiles are dead; the epilogue's staging comes later)
             if (tid == 0) {
-                const int prev = __hip_atomic_fetch_add(p.ks_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (prev == ks_S - 1) __hip_atomic_store(p.ks_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (self-cleaning: the next launch / graph replay finds zeros)
-                *flag = prev;
+                while (__hip_atomic_load(p.ks_cnt + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ks_S - 1) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(p.ks_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (self-cleaning: the next launch / graph replay finds zeros)
             }
             __syncthreads();
-            const bool last = *flag == ks_S - 1;
-            __syncthreads();
-            if (!last) return;
-            for (int q = 0; q < ks_S; ++q) {
+            for (int q = 0; q < ks_S - 1; ++q) {          // fixed order: own (last) K range + part 0 + part 1 ...
                 const float* src = wst + (long)q * ((long)NACC * NT) + tid;
 #pragma unroll
                 for (int a = 0; a < TN; ++a)
 #pragma unroll
                     for (int b = 0; b < TM; ++b)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = __hip_atomic_load(src + ((a * TM + b) * 16 + r) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            acc[a][b][r] = q == 0 ? v : acc[a][b][r] + v;
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            acc[a][b][r] += __hip_atomic_load(src + ((a * TM + b) * 16 + r) * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1901,6 +1893,12 @@ static int ksplit_plan(long M, int Cin, int Cout, int ntaps, int up, int wrap, b
     const long T = ((M + 255) / 256) * (Cout / 320);
     const int nch = Cin / 64;
     if (T < 64 || (gn_stats && T < 512)) return 1;
+    // Liveness of the waiting owners (conv_igemm_kernel): block ids are part-major and every XCD dispatches its share of them in order, so an XCD
+    // starts a launch's owners only after ALL of that launch's parts it was dealt -- one launch alone can never block itself.  Two launches side
+    // by side (the two branches' streams) could only block each other if some XCD's 32 CUs were ALL held by waiting owners of ONE launch (those of
+    // the other come behind that launch's own parts there): impossible below 32 owners per XCD, i.e. up to 248 tiles.  The rule stays below that;
+    // the forced part counts (knobs 2 - 4, 7, 8: single-stream tests and A/B tools) do not.
+    if (T > 248 && (kn == 1 || kn == 9)) return 1;
     if (kn >= 2 && kn <= 4) return kn <= nch ? kn : 1;
     // measured inside the step (profiles/r06_conv_ksplit_ab.log): launches below two rounds of the chip -- which otherwise take the 128 x 128 tile --
     // gain (- 3 ... - 4.7 ms per cfg2 step), the 640-tile launches (2.5 rounds -> five half rounds) LOSE 2 ms to the partial sums' round trip:
@@ -2033,9 +2031,9 @@ static int conv_fwd_impl(const void* x, const void* w_packed, const void* bias, 
         const int64_t tiles = Cout % 320 == 0 ? ((p.M + 255) / 256) * (Cout / 320) : 0;
         IM360_CHECK_ARG(S > 1, "conv_fwd_ksplit: im360_conv_ksplit_plan gives no K-split for this launch");
         IM360_CHECK_ARG(ks_ws && ks_cnt && ((uintptr_t)ks_ws % 16) == 0 && ((uintptr_t)ks_cnt % 4) == 0 && ks_cnt_n >= tiles &&
-                        ks_ws_bytes >= tiles * S * (int64_t)(160 * 512 * 4),
+                        ks_ws_bytes >= tiles * (S - 1) * (int64_t)(160 * 512 * 4),
                         "conv_fwd_ksplit: %ld tiles x %d parts need %ld workspace bytes and %ld zeroed counters", (long)tiles, S,
-                        (long)(tiles * S * (int64_t)(160 * 512 * 4)), (long)tiles);
+                        (long)(tiles * (S - 1) * (int64_t)(160 * 512 * 4)), (long)tiles);
         p.ksplit = S;
         p.ks_ws = (float*)ks_ws;
         p.ks_cnt = (int*)ks_cnt;
@@ -2067,7 +2065,7 @@ extern "C" __attribute__((visibility("default"))) int64_t im360_conv_ksplit_plan
     return ksplit_plan(N * Hout * Wout, (int)Cin, (int)Cout, (int)ntaps, up ? 1 : 0, wrap ? 1 : 0, gn_stats != 0);
 }
 
-// im360_conv_fwd with every output tile's K range split over im360_conv_ksplit_plan(...) workgroups (ConvParams::ksplit).  ks_ws: tiles x parts
+// im360_conv_fwd with every output tile's K range split over im360_conv_ksplit_plan(...) workgroups (ConvParams::ksplit).  ks_ws: tiles x (parts - 1)
 // x 327 680 bytes of scratch (tiles = ceil(N Hout Wout / 256) x Cout / 320); ks_cnt: `tiles` int32 counters, ZERO on entry, zero again on return.
 // Deterministic (fixed summation order), not bit-identical to the unsplit launch (another order of the fp32 partial sums).
 extern "C" __attribute__((visibility("default"))) int im360_conv_fwd_ksplit(const void* x, const void* w_packed, const void* bias, const void* temb,

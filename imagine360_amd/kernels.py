@@ -539,7 +539,7 @@ def conv2d(x, w_packed, cout, bias=None, stride=1, up=False, wrap=False, x_off=0
     parts = lib().im360_conv_ksplit_plan(N, hout, wout, Cin, cout, taps, int(up), int(wrap), int(gn is not None)) if taps == 9 else 1
     if parts > 1:
         tiles = -(-(N * hout * wout) // 256) * (cout // 320)
-        ws = torch.empty((tiles * parts * 160 * 512,), dtype=torch.float32, device=x.device)
+        ws = torch.empty((tiles * (parts - 1) * 160 * 512,), dtype=torch.float32, device=x.device)
         cnt = torch.zeros((tiles,), dtype=torch.int32, device=x.device)
         rc = lib().im360_conv_fwd_ksplit(_p(x), _p(w_packed), _p(bias), _p(temb), _p(res), _p(y),
                                          N, Hin, Win, Cin, hout, wout, cout, taps, stride, int(up), int(wrap), x_off, y_off,

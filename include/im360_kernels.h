@@ -172,11 +172,11 @@ int im360_conv_fwd(const void* x, const void* w_packed, const void* bias, const 
 int64_t im360_conv_gn_slabs(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps);
 
 /* K-split of a 3x3 convolution launch (ABI version 5): every 256 x 320 output tile is computed by `parts` workgroups, each over a
- * contiguous range of the 64-channel chunks of K; every part parks its fp32 accumulators in ks_ws and counts itself into ks_cnt, the part
- * that arrives last adds them in part order and runs the usual epilogue (no workgroup waits for another).  For launches whose tile count is not a whole number of rounds
+ * contiguous range of the 64-channel chunks of K; parts 0 .. parts - 2 park their fp32 accumulators in ks_ws, the last one (dispatched
+ * behind them) adds them in part order and runs the usual epilogue.  For launches whose tile count is not a whole number of rounds
  * of the chip's 256 CUs (perspective level 2 of cfg2: 640 tiles = 2.5 rounds) or below one round (level 3: 160 tiles).
  * im360_conv_ksplit_plan: parts this launch would run in (1 = none: call im360_conv_fwd; knob conv_ksplit 0 = never).
- * im360_conv_fwd_ksplit: im360_conv_fwd + the scratch: ks_ws >= tiles x parts x 327 680 bytes (tiles = ceil(N Hout Wout / 256)
+ * im360_conv_fwd_ksplit: im360_conv_fwd + the scratch: ks_ws >= tiles x (parts - 1) x 327 680 bytes (tiles = ceil(N Hout Wout / 256)
  * x Cout / 320), ks_cnt = `tiles` int32 counters, ZERO on entry and zero again on return.  Deterministic; not bit-identical to the
  * unsplit launch (another order of the fp32 partial sums).  Same call sites as im360_conv_fwd (animatediff/models/resnet.py:19-27). */
 int64_t im360_conv_ksplit_plan(int64_t N, int64_t Hout, int64_t Wout, int64_t Cin, int64_t Cout, int64_t ntaps,

@@ -193,6 +193,7 @@ def test_conv_k_split_planner_rule():
     assert plan(640, 16, 16, 640, 640) == 1            # level 1: 1280 tiles
     assert plan(32, 8, 16, 1280, 1280) in (2, 3, 4)    # panorama level 3 (pre-padded window, no wrap flag): 64 tiles
     assert plan(32, 8, 20, 1280, 1280, wrap=1) == 1    # wrap addressing: left alone by the rule
+    assert plan(32, 16, 36, 1280, 1280) == 1           # 288 tiles: above the rule's liveness bound (248 tiles = 31 waiting owners per XCD)
     assert plan(640, 4, 4, 1280, 1280, up=1) == 1 and plan(640, 4, 4, 1280, 1280, taps=1) == 1
     assert plan(640, 4, 4, 1280, 1280, gn=1) == 1      # statistics epilogue needs >= 512 tiles
     assert plan(640, 4, 4, 1280, 1000) == 1 and plan(640, 4, 4, 96, 1280) == 1      # not the 256 x 320 tile / not whole 64-channel chunks

@@ -190,7 +190,7 @@ def _rccl_job(rank, world, capture_two=False):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):          # (global mode forbids the NCCL watchdog thread's event queries during the capture: a flaky abort)
         static_out = round_trip(sh, static_in)
     res = []
     for src, want in ((qkv2, full2), (qkv, full)):
@@ -218,7 +218,7 @@ def _rccl_job(rank, world, capture_two=False):
     if not capture_two:
         return out
     graph2 = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph2, stream=s_main):
+    with torch.cuda.graph(graph2, stream=s_main, capture_error_mode="thread_local"):
         s_side.wait_stream(s_main)
         with torch.cuda.stream(s_side):
             out_b = round_trip(sh_b, in_b)
